@@ -1,0 +1,146 @@
+/*
+ * xna_basecaller.h -- C ABI of libxnacall.so, the MI355X (gfx950) implementation of the
+ * ub-bonito CRF basecalling hot path.
+ *
+ * The reference (CSB5/XNA_Basecaller) is 100 % Python; its device arithmetic lives in
+ * un-vendored CUDA wheels (torch/cuDNN, ont-seqdist-cuda 0.0.4, koi 0.0.5).  There is therefore
+ * no native reference interface to mirror: every entry point below replaces a *Python-level*
+ * operator of the reference, cited as file:line under /root/reference/ub-bonito/bonito/.
+ * The binding a maintainer adds on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions across the ABI.
+ *   - every function returns XB_OK (0) or a negative xb_status; xb_last_error(ctx) gives text.
+ *   - one xb_ctx per GPU; it owns a HIP stream and every device buffer it allocates.  A ctx is
+ *     used by one thread at a time (the reference calls compute_scores from ONE pipeline
+ *     thread, crf/basecall.py:109-111); distinct ctxs are independent.
+ *   - "host" entry points take host buffers owned by the caller and block until the result is
+ *     in them.  "_dev" entry points take device pointers valid on the ctx's device (e.g.
+ *     torch tensor data_ptr()), enqueue on the ctx stream and return without waiting; call
+ *     xb_synchronize before reading results.
+ *   - layouts are the reference's: signal (N, L) fp32 [= (N,1,L)], scores (T, N, C) fp32
+ *     time-major, labels / seq (N, T) int8.
+ */
+#ifndef XNA_BASECALLER_H
+#define XNA_BASECALLER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define XB_API __attribute__((visibility("default")))
+#else
+#define XB_API
+#endif
+
+typedef struct xb_ctx xb_ctx;
+
+typedef enum xb_status {
+    XB_OK = 0,
+    XB_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    XB_ERR_HIP = -2,          /* a HIP runtime call failed */
+    XB_ERR_NOMEM = -3,        /* host or device allocation failed */
+    XB_ERR_STATE = -4,        /* call out of order (e.g. weights not loaded) */
+    XB_ERR_DEVICE = -5,       /* a kernel reported an internal failure (e.g. sync timeout) */
+    XB_ERR_NO_GPU = -6        /* no usable gfx950 device */
+} xb_status;
+
+/* Arithmetic of the dense projections (Conv1d k19, LSTM, Linear). */
+typedef enum xb_precision {
+    XB_PREC_F16X3 = 0,        /* split-fp16 MFMA, 3 products, fp32 accumulate: |score err| ~1e-5 */
+    XB_PREC_F16 = 1           /* single fp16 MFMA, fp32 accumulate (the reference's model.half()) */
+} xb_precision;
+
+/*
+ * Model + geometry.  Mirrors config.toml [encoder]/[global_norm]/[labels]
+ * (models/xna_r9.4.1_e8_sup@v3.3/config.toml:1-29) and rnn_encoder() (crf/model.py:142-160).
+ */
+typedef struct xb_config {
+    int32_t n_base;           /* len(labels) - 1 : 4, 5 or 6                                   */
+    int32_t state_len;        /* [global_norm] state_len (3)                                   */
+    int32_t features;         /* [encoder] features (768); multiple of 32                      */
+    int32_t winlen;           /* [encoder] winlen (19)                                         */
+    int32_t stride;           /* [encoder] stride (5)                                          */
+    float scale;              /* [encoder] scale (5.0)                                         */
+    float blank_score;        /* [encoder] blank_score (2.0)                                   */
+    int32_t chunk_len;        /* samples per chunk L (basecaller chunksize); T = L / stride    */
+    int32_t max_batch;        /* largest N passed to any call                                  */
+    int32_t precision;        /* xb_precision                                                  */
+    int32_t lstm_mode;        /* 0 = auto, 1 = one launch per time step, 2 = persistent kernel */
+} xb_config;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  Replaces Model(config).to(device), util.py:295,365. */
+XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg);
+XB_API void xb_ctx_destroy(xb_ctx *ctx);
+/* Text of the last error on `ctx` (or of the last failed xb_ctx_create when ctx is NULL). */
+XB_API const char *xb_last_error(const xb_ctx *ctx);
+XB_API int xb_device_count(void);
+
+/*
+ * Load one tensor of the reference state dict (model.load_state_dict, util.py:354) in PyTorch
+ * layout, fp32, from host memory.  `name` is the inference-encoder key:
+ *   encoder.{0,1,2}.conv.{weight,bias}          Conv1d (out, in, k)
+ *   encoder.{4..8}.rnn.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0}   (4H, H) / (4H), gates i,f,g,o
+ *   encoder.9.linear.{weight,bias}              (n_base^(state_len+1), H)
+ * `n` is the element count and must match the shape implied by the config.
+ */
+XB_API int xb_load_weights(xb_ctx *ctx, const char *name, const float *host, int64_t n);
+/* Re-layout the loaded tensors for the kernels (model.eval()/.to(device)); requires all 28 tensors. */
+XB_API int xb_weights_ready(xb_ctx *ctx);
+
+/* ---- operators -------------------------------------------------------------------------- */
+
+/*
+ * Model.forward: scores = model(batch) (crf/basecall.py:53, crf/model.py:212-213, nn.py).
+ * signal (n, L) fp32.  scores (T, n, C): C = S*(n_base+1) when expand_blanks != 0 (the
+ * LinearCRFEncoder layout with the blank column, nn.py:123-130), else S*n_base.
+ */
+XB_API int xb_encode(xb_ctx *ctx, const float *signal, int n, int expand_blanks, float *scores);
+XB_API int xb_encode_dev(xb_ctx *ctx, const float *d_signal, int n, int expand_blanks, float *d_scores);
+
+/*
+ * SeqdistModel.decode_batch + path_to_str + the left-pack of compute_scores
+ * (crf/model.py:215-218, 92-100; crf/basecall.py:57-76).
+ * scores (T, n, C) fp32, C = S*(n_base+1) if has_blank else S*n_base (blank = cfg.blank_score).
+ * labels (n, T) int8 [optional]: per-step arg-max edge % (n_base+1).
+ * seq    (n, T) int8 [optional]: ASCII of alphabet[label] for label != 0, left-packed, zero padded.
+ * seq_len (n) int32 [optional].   alphabet: n_base+1 bytes, e.g. "NACGTXY".
+ */
+XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_blank,
+                     const char *alphabet, int8_t *labels, int8_t *seq, int32_t *seq_len);
+XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank,
+                         const char *alphabet, int8_t *d_labels, int8_t *d_seq, int32_t *d_seq_len);
+
+/* compute_scores (crf/basecall.py:27-82), viterbi branch: encode + decode without materialising
+ * the blank column or copying scores off the device. */
+XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet,
+                              int8_t *seq, int32_t *seq_len);
+XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet,
+                                  int8_t *d_seq, int32_t *d_seq_len);
+
+XB_API int xb_synchronize(xb_ctx *ctx);
+
+/* ---- introspection / measurement ---------------------------------------------------------- */
+
+enum { XB_STAGE_CONV = 0, XB_STAGE_LSTM_IN = 1, XB_STAGE_LSTM_REC = 2, XB_STAGE_LINEAR = 3,
+       XB_STAGE_DECODE = 4, XB_STAGE_COUNT = 5 };
+
+/* Turn per-stage HIP-event timing on/off (events are recorded on the ctx stream). */
+XB_API int xb_set_profiling(xb_ctx *ctx, int on);
+/* Accumulated per-stage device time (ms) and kernel launch counts since the last reset;
+ * synchronises the stream.  Either pointer may be NULL. */
+XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t launches[XB_STAGE_COUNT]);
+XB_API int xb_reset_stage_times(xb_ctx *ctx);
+/* Output time steps per chunk, states, score columns of the loaded config. */
+XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_noblank);
+XB_API const char *xb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XNA_BASECALLER_H */

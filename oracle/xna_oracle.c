@@ -1,0 +1,507 @@
+/*
+ * xna_oracle.c -- CPU restatement of the ub-bonito CRF basecalling hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (xna_basecaller_amd/) never
+ * links, imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" for the CRF arithmetic.  The reference delegates the
+ * forward/backward recursions to the third-party wheel ont-seqdist-cuda*==0.0.4
+ * (requirements-cuda113.txt:18), which is absent from /root/reference, CUDA-only and has
+ * no tests/golden vectors in the reference tree.  The recursions below restate seqdist's
+ * published algorithm (sparse.logZ / SequenceDist.posteriors with the Log and Max
+ * semirings) anchored on the reference's own call sites:
+ *   ub-bonito/bonito/crf/model.py:31-36   state/edge index table          -> xo_crf_idx
+ *   ub-bonito/bonito/crf/model.py:41-46   logZ(Ms, idx, alpha_0=0, beta_T=0, S)
+ *   ub-bonito/bonito/crf/model.py:63-76   (new_state, dropped_base) edge layout
+ *   ub-bonito/bonito/crf/model.py:92-95   viterbi = posteriors(., Max).argmax(2) % len(alphabet)
+ *   ub-bonito/bonito/crf/model.py:97-100  path_to_str                      -> xo_pack
+ *   ub-bonito/bonito/crf/model.py:215-218 decode_batch: posteriors(+1e-8).log() -> viterbi
+ * The encoder restatement (Conv1d/SiLU, LSTM, Linear/tanh/scale/blank pad) follows
+ *   ub-bonito/bonito/nn.py:57-68,112-133,176-193,216-220 and crf/model.py:138-160
+ * and IS pinned: tests/golden/ holds outputs of the reference's own nn.py modules run in
+ * this container (tests/golden/make_golden.py).
+ *
+ * Floating-point contract of the decode (shared, by specification, with the HIP kernels;
+ * the two implementations are written independently):
+ *   - all arithmetic in IEEE binary32, round-to-nearest-even, no contraction
+ *     (build with -ffp-contract=off), fused multiply-add only where fmaf() is written;
+ *   - exp/log are the fixed polynomial routines xo_expf/xo_logf below (cephes-style),
+ *     NOT libm, so that a CPU and a GPU produce the same bits;
+ *   - logsumexp over a list x_0..x_{n-1}:  m = max_k x_k;  s = exp(x_0-m); s += exp(x_k-m)
+ *     for k=1..n-1 in list order;  result = m + log(s);
+ *   - in-edges of state j are listed k = 0..nb (k=0 is the stay/blank edge);
+ *     out-edges of state i are listed stay first, then new base b = 0..nb-1;
+ *   - posterior of edge (t,j,k):  P = exp(((alpha_t[src] + M) + beta_{t+1}[j]) - logZ),
+ *     Q = log(P + 1e-8f);   logZ = logsumexp_j(alpha_T[j]) in order j = 0..S-1;
+ *   - max-marginal of edge c=j*E+k at time t: (amax_t[src] + Q) + bmax_{t+1}[j];
+ *     label[t] = (lowest flat index attaining the maximum) % E.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define XO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------ */
+/* Specified math                                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+static inline float xo_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t xo_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp(x): 0 for x < -87, argument clamped to 88 above. */
+static inline float xo_expf_i(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int32_t ni = (int32_t)n;
+    float s = xo_bits2f((uint32_t)(ni + 127) << 23);
+    return y * s;
+}
+
+/* log(x) for normal positive x. */
+static inline float xo_logf_i(float x)
+{
+    uint32_t ix = xo_f2bits(x);
+    int32_t e = (int32_t)(ix >> 23) - 127;
+    float m = xo_bits2f((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237309505f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+XO_API float xo_expf(float x) { return xo_expf_i(x); }
+XO_API float xo_logf(float x) { return xo_logf_i(x); }
+
+XO_API void xo_expf_array(const float *x, float *y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = xo_expf_i(x[i]);
+}
+XO_API void xo_logf_array(const float *x, float *y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = xo_logf_i(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* CRF state table (crf/model.py:31-36)                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+static int64_t ipow(int64_t b, int e) { int64_t r = 1; while (e-- > 0) r *= b; return r; }
+
+/* idx[j*E + 0] = j ; idx[j*E + k] = (k-1) * nb^(sl-1) + j / nb  for k >= 1 */
+XO_API void xo_crf_idx(int nb, int sl, int32_t *idx)
+{
+    const int64_t S = ipow(nb, sl), hi = ipow(nb, sl - 1);
+    const int E = nb + 1;
+    for (int64_t j = 0; j < S; ++j) {
+        idx[j * E] = (int32_t)j;
+        for (int k = 1; k < E; ++k) idx[j * E + k] = (int32_t)((k - 1) * hi + j / nb);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* decode_batch (crf/model.py:215-218)                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * scores : (T, N, Cin) fp32.  has_blank != 0: Cin = S*E with the stay score in column 0 of
+ *          every state row (LinearCRFEncoder expand_blanks layout, nn.py:123-130).
+ *          has_blank == 0: Cin = S*nb and the stay score is the constant `blank`.
+ * labels : (N, T) int8 out -- argmax % E per time step (0 = no base emitted).
+ * Optional outputs (may be NULL): alpha (T+1,N,S), beta (T+1,N,S), logz (N),
+ *          post (T,N,S*E) posteriors P, amax (T+1,N,S), bmax (T+1,N,S).
+ */
+XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_blank, float blank,
+                     int8_t *labels, float *alpha_out, float *beta_out, float *logz_out,
+                     float *post_out, float *amax_out, float *bmax_out)
+{
+    const int S = (int)ipow(nb, sl), E = nb + 1, C = S * E;
+    const int Cin = has_blank ? C : S * nb;
+    const int hi = (int)ipow(nb, sl - 1);
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)C);
+    if (!idx) return -1;
+    xo_crf_idx(nb, sl, idx);
+    int err = 0;
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        const size_t TS = (size_t)(T + 1) * S;
+        float *al = (float *)malloc(sizeof(float) * TS);
+        float *be = (float *)malloc(sizeof(float) * TS);
+        float *bm = (float *)malloc(sizeof(float) * TS);
+        float *M = (float *)malloc(sizeof(float) * (size_t)C);
+        float *am = (float *)malloc(sizeof(float) * 2 * (size_t)S);
+        if (!al || !be || !bm || !M || !am) {
+            err = -1;
+            free(al); free(be); free(bm); free(M); free(am);
+            continue;
+        }
+#define LOADM(t)                                                                                    \
+    do {                                                                                            \
+        const float *row = scores + ((size_t)(t) * N + n) * Cin;                                    \
+        if (has_blank) memcpy(M, row, sizeof(float) * (size_t)C);                                   \
+        else for (int j_ = 0; j_ < S; ++j_) {                                                       \
+            M[j_ * E] = blank;                                                                      \
+            for (int k_ = 1; k_ < E; ++k_) M[j_ * E + k_] = row[j_ * nb + k_ - 1];                  \
+        }                                                                                           \
+    } while (0)
+
+        /* ---- Log semiring forward: alpha ---- */
+        for (int j = 0; j < S; ++j) al[j] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            LOADM(t);
+            const float *a0 = al + (size_t)t * S;
+            float *a1 = al + (size_t)(t + 1) * S;
+            for (int j = 0; j < S; ++j) {
+                float x[16];
+                float m = -INFINITY;
+                for (int k = 0; k < E; ++k) {
+                    x[k] = M[j * E + k] + a0[idx[j * E + k]];
+                    m = x[k] > m ? x[k] : m;
+                }
+                float s = xo_expf_i(x[0] - m);
+                for (int k = 1; k < E; ++k) s += xo_expf_i(x[k] - m);
+                a1[j] = m + xo_logf_i(s);
+            }
+        }
+        float logZ;
+        {
+            const float *aT = al + (size_t)T * S;
+            float m = -INFINITY;
+            for (int j = 0; j < S; ++j) m = aT[j] > m ? aT[j] : m;
+            float s = xo_expf_i(aT[0] - m);
+            for (int j = 1; j < S; ++j) s += xo_expf_i(aT[j] - m);
+            logZ = m + xo_logf_i(s);
+        }
+        if (logz_out) logz_out[n] = logZ;
+
+        /* ---- Log semiring backward (beta) fused with Max semiring backward (bmax) ---- */
+        for (int i = 0; i < S; ++i) { be[(size_t)T * S + i] = 0.0f; bm[(size_t)T * S + i] = 0.0f; }
+        for (int t = T - 1; t >= 0; --t) {
+            LOADM(t);
+            const float *a0 = al + (size_t)t * S;
+            const float *b1 = be + (size_t)(t + 1) * S;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float *b0 = be + (size_t)t * S;
+            float *m0 = bm + (size_t)t * S;
+            for (int i = 0; i < S; ++i) {
+                /* out-edges of i: stay (j=i,k=0), then new base b: j=(i%hi)*nb+b, k=i/hi+1 */
+                float y[16], q[16];
+                int dst[16];
+                const int kk = i / hi + 1;
+                dst[0] = i;
+                for (int b = 0; b < nb; ++b) dst[b + 1] = (i % hi) * nb + b;
+                float m = -INFINITY;
+                for (int e = 0; e < E; ++e) {
+                    const int j = dst[e];
+                    const float mv = M[j * E + (e == 0 ? 0 : kk)];
+                    y[e] = mv + b1[j];
+                    m = y[e] > m ? y[e] : m;
+                    const float xx = ((a0[i] + mv) + b1[j]) - logZ;
+                    const float P = xo_expf_i(xx);
+                    q[e] = xo_logf_i(P + 1e-8f);
+                    if (post_out) post_out[((size_t)t * N + n) * C + (size_t)j * E + (e == 0 ? 0 : kk)] = P;
+                }
+                float s = xo_expf_i(y[0] - m);
+                for (int e = 1; e < E; ++e) s += xo_expf_i(y[e] - m);
+                b0[i] = m + xo_logf_i(s);
+                float mm = q[0] + m1[dst[0]];
+                for (int e = 1; e < E; ++e) {
+                    const float v = q[e] + m1[dst[e]];
+                    mm = v > mm ? v : mm;
+                }
+                m0[i] = mm;
+            }
+        }
+
+        /* ---- Max semiring forward with per-step arg-max of the max-marginals ---- */
+        float *am0 = am, *am1 = am + S;
+        for (int j = 0; j < S; ++j) am0[j] = 0.0f;
+        if (amax_out) for (int j = 0; j < S; ++j) amax_out[(size_t)n * S + j] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            LOADM(t);
+            const float *a0 = al + (size_t)t * S;
+            const float *b1 = be + (size_t)(t + 1) * S;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float best = -INFINITY;
+            int bestc = 0;
+            for (int j = 0; j < S; ++j) {
+                float mm = -INFINITY;
+                for (int k = 0; k < E; ++k) {
+                    const int src = idx[j * E + k];
+                    const float xx = ((a0[src] + M[j * E + k]) + b1[j]) - logZ;
+                    const float Q = xo_logf_i(xo_expf_i(xx) + 1e-8f);
+                    const float v = Q + am0[src];
+                    mm = v > mm ? v : mm;
+                    const float sc = (am0[src] + Q) + m1[j];
+                    if (sc > best) { best = sc; bestc = j * E + k; }
+                }
+                am1[j] = mm;
+            }
+            labels[(size_t)n * T + t] = (int8_t)(bestc % E);
+            if (amax_out) memcpy(amax_out + ((size_t)(t + 1) * N + n) * S, am1, sizeof(float) * (size_t)S);
+            float *tmp = am0; am0 = am1; am1 = tmp;
+        }
+#undef LOADM
+        if (alpha_out) for (int t = 0; t <= T; ++t)
+            memcpy(alpha_out + ((size_t)t * N + n) * S, al + (size_t)t * S, sizeof(float) * (size_t)S);
+        if (beta_out) for (int t = 0; t <= T; ++t)
+            memcpy(beta_out + ((size_t)t * N + n) * S, be + (size_t)t * S, sizeof(float) * (size_t)S);
+        if (bmax_out) for (int t = 0; t <= T; ++t)
+            memcpy(bmax_out + ((size_t)t * N + n) * S, bm + (size_t)t * S, sizeof(float) * (size_t)S);
+        free(al); free(be); free(bm); free(M); free(am);
+    }
+    free(idx);
+    return err;
+}
+
+/*
+ * path_to_str (crf/model.py:97-100) + the left-pack of compute_scores (crf/basecall.py:60-67):
+ * seq[n, 0:len] = alphabet[label] for label != 0, zero padded to T; qstring 'O' (79) likewise.
+ * alphabet: E bytes, e.g. "NACGTXY".
+ */
+XO_API void xo_pack(const int8_t *labels, int N, int T, const char *alphabet,
+                    int8_t *seq, int8_t *qstring, int32_t *seq_len)
+{
+    for (int n = 0; n < N; ++n) {
+        int len = 0;
+        for (int t = 0; t < T; ++t) {
+            const int l = labels[(size_t)n * T + t];
+            if (l != 0) {
+                seq[(size_t)n * T + len] = (int8_t)alphabet[l];
+                if (qstring) qstring[(size_t)n * T + len] = 79;
+                ++len;
+            }
+        }
+        for (int t = len; t < T; ++t) {
+            seq[(size_t)n * T + t] = 0;
+            if (qstring) qstring[(size_t)n * T + t] = 0;
+        }
+        if (seq_len) seq_len[n] = len;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Encoder (nn.py) -- fp32, tolerance-compared (summation order not part of a contract)  */
+/* ------------------------------------------------------------------------------------ */
+
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/*
+ * Conv1d + bias + SiLU (nn.py:57-68; torch.nn.Conv1d cross-correlation).
+ * x: (N, Cin, L)   w: (Cout, Cin, K)   b: (Cout)   y: (N, Cout, Lout),
+ * Lout = (L + 2*pad - K)/stride + 1.
+ */
+XO_API void xo_conv1d_silu(const float *x, int N, int Cin, int L, const float *w, const float *b,
+                           int Cout, int K, int stride, int pad, float *y)
+{
+    const int Lout = (L + 2 * pad - K) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int co = 0; co < Cout; ++co) {
+            float *yo = y + ((size_t)n * Cout + co) * Lout;
+            for (int t = 0; t < Lout; ++t) {
+                float acc = b ? b[co] : 0.0f;
+                const int base = t * stride - pad;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float *xi = x + ((size_t)n * Cin + ci) * L;
+                    const float *wi = w + ((size_t)co * Cin + ci) * K;
+                    for (int k = 0; k < K; ++k) {
+                        const int p = base + k;
+                        if (p >= 0 && p < L) acc += wi[k] * xi[p];
+                    }
+                }
+                yo[t] = acc * sigmoidf_(acc);
+            }
+        }
+}
+
+/* C(M,Nn) = A(M,K) * B(Nn,K)^T + bias(Nn) ; row-major, B given as [out][in] (torch layout). */
+static void gemm_nt_bias(const float *A, const float *B, const float *bias, float *C,
+                         int64_t M, int Nn, int K)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t m0 = 0; m0 < M; m0 += 8) {
+        const int64_t mb = (M - m0) < 8 ? (M - m0) : 8;
+        for (int n0 = 0; n0 < Nn; ++n0) {
+            const float *bp = B + (size_t)n0 * K;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t mi = 0; mi < mb; ++mi) {
+                const float *ap = A + (size_t)(m0 + mi) * K;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+                int k = 0;
+                for (; k + 8 <= K; k += 8) {
+                    s0 += ap[k] * bp[k];         s1 += ap[k + 1] * bp[k + 1];
+                    s2 += ap[k + 2] * bp[k + 2]; s3 += ap[k + 3] * bp[k + 3];
+                    s4 += ap[k + 4] * bp[k + 4]; s5 += ap[k + 5] * bp[k + 5];
+                    s6 += ap[k + 6] * bp[k + 6]; s7 += ap[k + 7] * bp[k + 7];
+                }
+                float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+                for (; k < K; ++k) s += ap[k] * bp[k];
+                acc[mi] = s;
+            }
+            for (int64_t mi = 0; mi < mb; ++mi)
+                C[(size_t)(m0 + mi) * Nn + n0] = acc[mi] + (bias ? bias[n0] : 0.0f);
+        }
+    }
+}
+
+/*
+ * One torch.nn.LSTM(size, insize) layer, seq-first, zero initial state, optional reverse
+ * (nn.py:176-193: flip -> run -> flip).  Gate order i,f,g,o (PyTorch).
+ * x: (T, N, I)  w_ih: (4H, I)  w_hh: (4H, H)  b_ih,b_hh: (4H)  y: (T, N, H)
+ */
+XO_API int xo_lstm(const float *x, int T, int N, int I, int H, const float *w_ih,
+                   const float *w_hh, const float *b_ih, const float *b_hh, int reverse, float *y)
+{
+    const size_t G = (size_t)4 * H;
+    float *gin = (float *)malloc(sizeof(float) * (size_t)T * N * G);
+    float *g = (float *)malloc(sizeof(float) * (size_t)N * G);
+    float *h = (float *)calloc((size_t)N * H, sizeof(float));
+    float *c = (float *)calloc((size_t)N * H, sizeof(float));
+    float *bsum = (float *)malloc(sizeof(float) * G);
+    if (!gin || !g || !h || !c || !bsum) { free(gin); free(g); free(h); free(c); free(bsum); return -1; }
+    for (size_t i = 0; i < G; ++i) bsum[i] = (b_ih ? b_ih[i] : 0.0f) + (b_hh ? b_hh[i] : 0.0f);
+    gemm_nt_bias(x, w_ih, bsum, gin, (int64_t)T * N, (int)G, I);
+    for (int s = 0; s < T; ++s) {
+        const int t = reverse ? T - 1 - s : s;
+        gemm_nt_bias(h, w_hh, NULL, g, N, (int)G, H);
+        const float *gi = gin + (size_t)t * N * G;
+#pragma omp parallel for schedule(static)
+        for (int n = 0; n < N; ++n)
+            for (int u = 0; u < H; ++u) {
+                const size_t o = (size_t)n * G;
+                const float ig = sigmoidf_(g[o + u] + gi[o + u]);
+                const float fg = sigmoidf_(g[o + H + u] + gi[o + H + u]);
+                const float gg = tanhf(g[o + 2 * H + u] + gi[o + 2 * H + u]);
+                const float og = sigmoidf_(g[o + 3 * H + u] + gi[o + 3 * H + u]);
+                const float cn = fg * c[(size_t)n * H + u] + ig * gg;
+                c[(size_t)n * H + u] = cn;
+                const float hn = og * tanhf(cn);
+                h[(size_t)n * H + u] = hn;
+                y[((size_t)t * N + n) * H + u] = hn;
+            }
+    }
+    free(gin); free(g); free(h); free(c); free(bsum);
+    return 0;
+}
+
+/*
+ * LinearCRFEncoder.forward (nn.py:112-133): scale * tanh(W x + b), then (expand != 0) a column
+ * of `blank` is inserted in front of every group of nb outputs.
+ * x: (M, I)  w: (O, I)  b: (O)   y: (M, O) or (M, O/nb*(nb+1))
+ */
+XO_API int xo_linear_crf(const float *x, int64_t M, int I, const float *w, const float *b, int O,
+                         float scale, int nb, int expand, float blank, float *y)
+{
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)M * O);
+    if (!tmp) return -1;
+    gemm_nt_bias(x, w, b, tmp, M, O, I);
+    const int E = nb + 1, S = O / nb;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const float *ti = tmp + (size_t)m * O;
+        if (expand) {
+            float *yo = y + (size_t)m * S * E;
+            for (int s = 0; s < S; ++s) {
+                yo[s * E] = blank;
+                for (int k = 0; k < nb; ++k) yo[s * E + 1 + k] = scale * tanhf(ti[s * nb + k]);
+            }
+        } else {
+            float *yo = y + (size_t)m * O;
+            for (int o = 0; o < O; ++o) yo[o] = scale * tanhf(ti[o]);
+        }
+    }
+    free(tmp);
+    return 0;
+}
+
+/*
+ * Whole encoder, rnn_encoder() of crf/model.py:142-160 (inference form, no dropout):
+ * conv(1->4,k5,p2) conv(4->16,k5,p2) conv(16->F,k=winlen,s=stride,p=winlen/2) each +SiLU,
+ * permute to (T,N,F), 5 LSTMs reverse,fwd,reverse,fwd,reverse, LinearCRFEncoder.
+ * weights: array of 28 pointers in state-dict order
+ *   conv{0,1,2}.{weight,bias}, lstm{0..4}.{weight_ih,weight_hh,bias_ih,bias_hh}, linear.{weight,bias}
+ * signal: (N, L)   scores: (T, N, S*E) if expand else (T, N, S*nb)
+ */
+XO_API int xo_encode(const float *signal, int N, int L, const float *const *weights, int features,
+                     int winlen, int stride, int nb, int sl, float scale, float blank, int expand,
+                     float *scores, float *lstm_out /* optional (T,N,F): input of the linear */)
+{
+    const int F = features;
+    const int T = (L + 2 * (winlen / 2) - winlen) / stride + 1;
+    float *c1 = (float *)malloc(sizeof(float) * (size_t)N * 4 * L);
+    float *c2 = (float *)malloc(sizeof(float) * (size_t)N * 16 * L);
+    float *c3 = (float *)malloc(sizeof(float) * (size_t)N * F * T);
+    float *xa = (float *)malloc(sizeof(float) * (size_t)T * N * F);
+    float *xb = (float *)malloc(sizeof(float) * (size_t)T * N * F);
+    int rc = -1;
+    if (!c1 || !c2 || !c3 || !xa || !xb) goto done;
+    xo_conv1d_silu(signal, N, 1, L, weights[0], weights[1], 4, 5, 1, 2, c1);
+    xo_conv1d_silu(c1, N, 4, L, weights[2], weights[3], 16, 5, 1, 2, c2);
+    xo_conv1d_silu(c2, N, 16, L, weights[4], weights[5], F, winlen, stride, winlen / 2, c3);
+    /* Permute([2,0,1]): (N,F,T) -> (T,N,F) */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < N; ++n)
+            for (int f = 0; f < F; ++f)
+                xa[((size_t)t * N + n) * F + f] = c3[((size_t)n * F + f) * T + t];
+    {
+        float *src = xa, *dst = xb;
+        for (int l = 0; l < 5; ++l) {
+            const float *const *w = weights + 6 + 4 * l;
+            if (xo_lstm(src, T, N, F, F, w[0], w[1], w[2], w[3], (l % 2) == 0, dst)) goto done;
+            float *tmp = src; src = dst; dst = tmp;
+        }
+        if (lstm_out) memcpy(lstm_out, src, sizeof(float) * (size_t)T * N * F);
+        const int O = (int)ipow(nb, sl + 1);
+        if (xo_linear_crf(src, (int64_t)T * N, F, weights[26], weights[27], O, scale, nb, expand,
+                          blank, scores)) goto done;
+    }
+    rc = 0;
+done:
+    free(c1); free(c2); free(c3); free(xa); free(xb);
+    return rc;
+}
+
+XO_API int xo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

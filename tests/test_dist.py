@@ -1,0 +1,71 @@
+"""CPU: the N>1 path (round-robin sharding + gather of called sequences) with world_size 2 over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["XB_ROOT"])
+import numpy as np, torch
+from xna_basecaller_amd import dist as xd
+rank, world = xd.init_from_env(backend="gloo")
+assert world == 2
+units = ["read%03d" % i for i in range(11)]
+mine = list(xd.shard(units))
+assert [i for i, _ in mine] == list(range(rank, 11, 2))
+recs = [(i, u, "ACGTXY"[: 1 + i % 6] * (1 + i % 3), "O" * ((1 + i % 6) * (1 + i % 3))) for i, u in mine]
+if rank == 1:
+    recs = recs[::-1]           # arrival order on a rank must not matter
+merged = xd.gather_called(recs, dst=0)
+if rank == 0:
+    assert [m[0] for m in merged] == list(range(11))
+    assert [m[1] for m in merged] == units
+    for i, rid, seq, q in merged:
+        assert seq == "ACGTXY"[: 1 + i % 6] * (1 + i % 3) and len(q) == len(seq)
+else:
+    assert merged is None
+# empty shard on one rank
+merged = xd.gather_called([(0, "only", "AC", "OO")] if rank == 0 else [], dst=0)
+if rank == 0:
+    assert merged == [(0, "only", "AC", "OO")]
+# fixed-shape gather used by bench.py
+seq = torch.full((3, 8), rank + 65, dtype=torch.int8)
+lens = torch.tensor([rank, 2, 3], dtype=torch.int32)
+s, l = xd.gather_packed(seq, lens)
+assert s.shape == (2, 3, 8) and l.shape == (2, 3)
+assert s[0, 0, 0].item() == 65 and s[1, 2, 7].item() == 66 and l[:, 0].tolist() == [0, 1]
+xd.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_and_gather_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, XB_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
+def test_single_process_paths():
+    from xna_basecaller_amd import dist as xd
+    assert xd.rank() == 0 and xd.world_size() == 1
+    assert list(xd.shard("abc")) == [(0, "a"), (1, "b"), (2, "c")]
+    assert xd.gather_called([(2, "b", "A", "O"), (0, "a", "C", "O")]) == [(0, "a", "C", "O"), (2, "b", "A", "O")]

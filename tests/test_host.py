@@ -1,0 +1,167 @@
+"""CPU: host-side mirror of the reference interface (util / reads / io / toml / model container) against the
+golden fixtures produced by the reference's own functions (tests/golden/make_golden.py)."""
+import io as _io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SHIPPED_CONFIG, make_config
+from xna_basecaller_amd import toml_lite, util
+from xna_basecaller_amd import io as xio
+from xna_basecaller_amd import reads as xreads
+
+
+def test_chunk_and_stitch_match_reference():
+    cases = json.load(open(os.path.join(GOLDEN, "chunk_stitch.json")))["cases"]
+    assert len(cases) >= 15
+    for c in cases:
+        length, L, ov, stride = c["length"], c["chunksize"], c["overlap"], c["stride"]
+        sig = np.arange(length, dtype=np.float32) + 1.0
+        ch = util.chunk(sig, L, ov)
+        assert ch.shape == (c["n_chunks"], 1, L)
+        assert (ch[:, 0, 0].astype(np.int64) - 1).tolist() == c["starts"]
+        assert int((ch[0, 0] == 0).sum()) == c["left_pad"]
+        if length >= L:
+            assert util.chunk_starts(length, L, ov).tolist() == c["starts"]
+        T = L // stride
+        rows = np.arange(c["n_chunks"] * T, dtype=np.int32).reshape(c["n_chunks"], T) + 1
+        st = util.stitch(rows, L, ov, length, stride)
+        assert (np.asarray(st).astype(np.int64) - 1).tolist() == c["stitch"]
+        if c["n_chunks"] > 1:
+            st = util.stitch(rows, L, ov, length, stride, reverse=True)
+            assert (np.asarray(st).astype(np.int64) - 1).tolist() == c["stitch_reverse"]
+
+
+def test_stitch_survey_example():
+    # len 23000, L 10000, ov 500 -> starts 0, 3500, 13000 and 4600 slots
+    assert util.chunk_starts(23000, 10000, 500).tolist() == [0, 3500, 13000]
+    rows = np.zeros((3, 2000), np.int8)
+    assert util.stitch(rows, 10000, 500, 23000, 5).shape == (4600,)
+
+
+def test_batchify_unbatchify_match_reference():
+    cases = json.load(open(os.path.join(GOLDEN, "batchify.json")))["cases"]
+    for c in cases:
+        items = [(("read%d" % i, 0, n * 10), np.full((n, 1, 6), float(i), np.float32)) for i, n in enumerate(c["n_chunks"])]
+        batches = list(util.batchify(iter(items), c["batchsize"]))
+        keys = [[[list(k[0]), list(k[1])] for k in ks] for ks, v in batches]
+        assert keys == c["keys"]
+        assert [int(v.shape[0]) for ks, v in batches] == c["batch_sizes"]
+        un = [[list(k), int(v.shape[0]), float(v[0, 0, 0])] for k, v in util.unbatchify(iter(batches))]
+        assert un == c["unbatch"]
+
+
+def test_unbatchify_dict_values():
+    items = [(("a",), np.zeros((3, 1, 4), np.float32)), (("b",), np.ones((4, 1, 4), np.float32))]
+    batches = [(ks, {"x": v[:, 0, :2], "y": v[:, 0, 0]}) for ks, v in util.batchify(iter(items), 2)]
+    out = list(util.unbatchify(iter(batches)))
+    assert [k for k, _ in out] == [("a",), ("b",)]
+    assert out[0][1]["x"].shape == (3, 2) and out[1][1]["y"].tolist() == [1, 1, 1, 1]
+
+
+def test_signal_preparation_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "signal_prep.npz"))
+    offset, rng, digi = int(z["offset"]), float(z["range"]), float(z["digitisation"])
+    for i in range(int(z["n"])):
+        raw = z["raw%d" % i]
+        scaled = np.array((rng / digi) * (raw + offset), dtype=np.float32)
+        t0, tlen = xreads.trim(scaled[:8000])
+        assert [t0, tlen] == z["trim%d" % i].tolist()
+        trimmed = scaled[t0:]
+        med, mad = xreads.med_mad(trimmed)
+        assert np.allclose([med, mad], z["medmad%d" % i], rtol=0, atol=0)
+        attrs = dict(read_id="r%d" % i, range=rng, digitisation=digi, offset=offset, sampling_rate=4000.0)
+        read = xreads.Read(raw, attrs, "x.xsig.npz")
+        assert read.signal.dtype == np.float32 or read.signal.dtype == np.float64
+        assert np.array_equal(np.asarray(read.signal, np.float32), z["signal%d" % i])
+        assert np.array_equal(np.asarray(xreads.norm_by_noisiest_section(trimmed[:7000]), np.float32), z["noisiest%d" % i])
+
+
+def test_bundle_roundtrip(tmp_path):
+    z = np.load(os.path.join(GOLDEN, "signal_prep.npz"))
+    recs = []
+    for i in range(3):
+        recs.append((z["raw%d" % i], dict(read_id="read-%d" % i, range=float(z["range"]), digitisation=float(z["digitisation"]),
+                                           offset=int(z["offset"]), sampling_rate=4000.0, run_id="run1", channel_number="7",
+                                           start_mux=2, read_number=i, start_time=4000 * i, duration=len(z["raw%d" % i]),
+                                           exp_start_time="2021-06-01T10:00:00Z")))
+    xreads.write_bundle(str(tmp_path / "a.xsig.npz"), recs)
+    got = list(xreads.get_reads(str(tmp_path)))
+    assert [r.read_id for r in got] == ["read-0", "read-1", "read-2"]
+    assert np.array_equal(np.asarray(got[1].signal, np.float32), z["signal1"])
+    assert got[2].tagdata() == ["mx:i:2", "ch:i:7", "st:Z:2021-06-01T10:00:02", "rn:i:2", "f5:Z:a.xsig.npz"]
+    only = list(xreads.get_reads(str(tmp_path), read_ids={"read-1"}))
+    assert [r.read_id for r in only] == ["read-1"]
+    skip = list(xreads.get_reads(str(tmp_path), read_ids={"read-1"}, skip=True))
+    assert [r.read_id for r in skip] == ["read-0", "read-2"]
+
+
+def test_toml_roundtrip_shipped_config():
+    text = toml_lite.dumps(SHIPPED_CONFIG)
+    assert toml_lite.loads(text) == SHIPPED_CONFIG
+    # the reference file's own formatting: trailing comma arrays, spaces inside brackets
+    cfg = toml_lite.loads('[labels]\nlabels = [ "N", "A", "C", "G", "T", "X", "Y",]\n\n[encoder]\nscale = 5.0\nstride = 5\n'
+                          'rnn_type = "lstm" # comment\nflag = true\n[a.b]\nx = [1,\n 2,\n 3]\n')
+    assert cfg["labels"]["labels"] == list("NACGTXY")
+    assert cfg["encoder"] == {"scale": 5.0, "stride": 5, "rnn_type": "lstm", "flag": True}
+    assert cfg["a"]["b"]["x"] == [1, 2, 3]
+
+
+def test_match_names_and_model_container():
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))
+    from xna_basecaller_amd.crf.model import Model
+    mm = meta["match_names"]
+    model = Model(make_config(32))
+    assert list(model.state_dict().keys()) == mm["model_keys"]
+    import torch
+    sd = {k: torch.zeros(s) for k, s in zip(mm["train_keys"], mm["train_shapes"])}
+    remap = util.match_names(sd, model)
+    assert [[k, v] for k, v in remap.items()] == mm["remap"]
+    # shipped geometry: 24 854 904 parameters, stride 5, 1512 scores, idx table
+    full = Model(make_config(768))
+    assert sum(p.numel() for p in full.parameters()) == 24854904
+    assert full.stride == 5 and full.seqdist.n_score() == 1512
+    assert full.seqdist.idx.shape == (216, 7)
+    assert full.seqdist.idx[215].tolist() == [215, 35, 71, 107, 143, 179, 215]
+    assert full.encoder[-1].expand_blanks and full.encoder[-1].blank_score == 2.0
+    z = np.load(os.path.join(GOLDEN, "crf_idx.npz"))
+    assert np.array_equal(full.seqdist.idx.numpy(), z["idx_nb6"])
+    assert full.seqdist.path_to_str(np.array([0, 1, 0, 6, 5, 0])) == "AYX"
+
+
+def test_mean_qscore_and_fastq_record():
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))
+    for q, v in meta["qscore"]:
+        assert abs(util.mean_qscore_from_qstring(q) - v) < 1e-9
+    assert util.mean_qscore_from_qstring("O" * 12) == pytest.approx(40.0)
+    fd = _io.StringIO()
+    xio.write_fastq("rid", "ACGX", "OOOO", fd=fd, tags=["RG:Z:run_m", "qs:i:40", "mx:i:1"])
+    assert fd.getvalue() == "@rid RG:Z:run_m\tqs:i:40\tmx:i:1\nACGX\n+\nOOOO\n"
+
+
+def test_writer_fastq_and_summary(tmp_path):
+    reads = [xreads.SyntheticRead("r%d" % i, np.zeros(100 * (i + 1), np.float32), run_id="runA") for i in range(3)]
+    results = [(reads[0], {"sequence": "ACGT", "qstring": "OOOO"}), (reads[1], {"sequence": "", "qstring": ""}),
+               (reads[2], {"sequence": "XY", "qstring": "OO"})]
+    fd = _io.StringIO()
+    w = xio.Writer("wfq", iter(results), fd=fd, group_key="model_dir", summary=str(tmp_path / "s.tsv"))
+    w.start()
+    w.join()
+    assert w.error is None
+    assert w.log == [("r0", 100), ("r2", 300)]          # the empty sequence is skipped
+    lines = fd.getvalue().split("\n")
+    assert lines[0] == "@r0 RG:Z:runA_model_dir\tqs:i:40\tmx:i:1\tch:i:1\tst:Z:1970-01-01T00:00:00\trn:i:0\tf5:Z:synthetic.xsig.npz"
+    assert lines[1:4] == ["ACGT", "+", "OOOO"]
+    rows = open(tmp_path / "s.tsv").read().strip().split("\n")
+    assert rows[0].split("\t")[:3] == ["filename", "read_id", "run_id"] and len(rows) == 3
+
+
+def test_cli_argparser_defaults():
+    from xna_basecaller_amd.cli.basecaller import argparser
+    from argparse import ArgumentParser
+    p = ArgumentParser(parents=[argparser()])
+    a = p.parse_args(["m", "r", "--batch", "98", "--read-ids", "ids.tsv"])      # prefix abbreviation, eval_model.sh:29
+    assert a.batchsize == 98 and a.device == "cuda" and a.seed == 25 and a.weights == "0"
+    assert a.chunksize is None and a.overlap is None and a.use_koi is True and a.quantize is None

@@ -1,0 +1,196 @@
+"""
+ctypes binding of libxnacall.so (include/xna_basecaller.h).  There is NO fallback: if the
+library is missing or no gfx950 GPU is present the product path raises, it never computes on
+the CPU (the CPU restatement lives in oracle/ and is test infrastructure only).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxnacall.so")
+_lib = None
+
+XB_STAGE_NAMES = ("conv", "lstm_in", "lstm_rec", "linear", "decode")
+XB_PREC_F16X3, XB_PREC_F16 = 0, 1
+
+EXPORTS = [
+    "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",
+    "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev",
+    "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
+    "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version",
+]
+
+
+class XbConfig(C.Structure):
+    _fields_ = [("n_base", C.c_int32), ("state_len", C.c_int32), ("features", C.c_int32),
+                ("winlen", C.c_int32), ("stride", C.c_int32), ("scale", C.c_float),
+                ("blank_score", C.c_float), ("chunk_len", C.c_int32), ("max_batch", C.c_int32),
+                ("precision", C.c_int32), ("lstm_mode", C.c_int32)]
+
+
+class XbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libxnacall error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (csrc/Makefile; hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(no CPU fallback exists for the MI355X path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    lib.xb_ctx_create.argtypes = [C.POINTER(vp), ip, C.POINTER(XbConfig)]
+    lib.xb_ctx_destroy.argtypes = [vp]
+    lib.xb_ctx_destroy.restype = None
+    lib.xb_last_error.argtypes = [vp]
+    lib.xb_last_error.restype = C.c_char_p
+    lib.xb_version.restype = C.c_char_p
+    lib.xb_load_weights.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.xb_weights_ready.argtypes = [vp]
+    lib.xb_encode.argtypes = [vp, vp, ip, ip, vp]
+    lib.xb_encode_dev.argtypes = [vp, vp, ip, ip, vp]
+    lib.xb_decode.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, vp, vp, vp]
+    lib.xb_decode_dev.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, vp, vp, vp]
+    lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
+    lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
+    lib.xb_synchronize.argtypes = [vp]
+    lib.xb_set_profiling.argtypes = [vp, ip]
+    lib.xb_get_stage_times.argtypes = [vp, vp, vp]
+    lib.xb_reset_stage_times.argtypes = [vp]
+    lib.xb_geometry.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load().xb_device_count())
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise RuntimeError("no HIP device visible: the xna_basecaller_amd hot path runs on MI355X (gfx950) only")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a)          # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class Context:
+    """One xb_ctx: a GPU, a stream, the device copies of the weights and all workspaces."""
+
+    def __init__(self, device, n_base, state_len, features, winlen, stride, scale, blank_score,
+                 chunk_len, max_batch, precision=XB_PREC_F16X3, lstm_mode=0):
+        self.lib = load()
+        self.cfg = XbConfig(n_base, state_len, features, winlen, stride, scale, blank_score, chunk_len,
+                            max_batch, precision, lstm_mode)
+        h = C.c_void_p()
+        rc = self.lib.xb_ctx_create(C.byref(h), int(device), C.byref(self.cfg))
+        if rc:
+            raise XbError(rc, (self.lib.xb_last_error(None) or b"").decode())
+        self.h = h
+        T, S, Cb, Cn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.xb_geometry(self.h, C.byref(T), C.byref(S), C.byref(Cb), C.byref(Cn))
+        self.T, self.S, self.C_blank, self.C_noblank = T.value, S.value, Cb.value, Cn.value
+        self.n_base, self.chunk_len, self.max_batch = n_base, chunk_len, max_batch
+
+    def _check(self, rc):
+        if rc:
+            raise XbError(rc, (self.lib.xb_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.xb_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict):
+        """state_dict: name -> fp32 array in PyTorch layout (the 28 inference-encoder tensors)."""
+        for k, v in state_dict.items():
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+            self._check(self.lib.xb_load_weights(self.h, k.encode(), a.ctypes.data, a.size))
+        self._check(self.lib.xb_weights_ready(self.h))
+
+    # ---- host-buffer operators ---------------------------------------------------------
+    def encode(self, signal, expand_blanks=True):
+        signal = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1, self.chunk_len)
+        n = signal.shape[0]
+        scores = np.empty((self.T, n, self.C_blank if expand_blanks else self.C_noblank), dtype=np.float32)
+        self._check(self.lib.xb_encode(self.h, signal.ctypes.data, n, int(bool(expand_blanks)), scores.ctypes.data))
+        return scores
+
+    def decode(self, scores, alphabet, has_blank=None, want_labels=False):
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, n, Cin = scores.shape
+        if has_blank is None:
+            has_blank = Cin == self.C_blank
+        if Cin != (self.C_blank if has_blank else self.C_noblank):
+            raise ValueError("scores last dim %d does not match the model (%d with blanks, %d without)"
+                             % (Cin, self.C_blank, self.C_noblank))
+        labels = np.empty((n, T), dtype=np.int8) if want_labels else None
+        seq = np.empty((n, T), dtype=np.int8)
+        lens = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.xb_decode(self.h, scores.ctypes.data, T, n, int(bool(has_blank)),
+                                       "".join(alphabet).encode(), _ptr(labels), seq.ctypes.data, lens.ctypes.data))
+        return (seq, lens, labels) if want_labels else (seq, lens)
+
+    def basecall_chunks(self, signal, alphabet):
+        signal = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1, self.chunk_len)
+        n = signal.shape[0]
+        seq = np.empty((n, self.T), dtype=np.int8)
+        lens = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.xb_basecall_chunks(self.h, signal.ctypes.data, n, "".join(alphabet).encode(),
+                                                seq.ctypes.data, lens.ctypes.data))
+        return seq, lens
+
+    # ---- device-pointer operators (pointers are ints, e.g. torch data_ptr()) -----------------
+    def encode_dev(self, d_signal, n, expand_blanks, d_scores):
+        self._check(self.lib.xb_encode_dev(self.h, _ptr(d_signal), n, int(bool(expand_blanks)), _ptr(d_scores)))
+
+    def decode_dev(self, d_scores, T, n, has_blank, alphabet, d_labels, d_seq, d_len):
+        ab = None if alphabet is None else "".join(alphabet).encode()
+        self._check(self.lib.xb_decode_dev(self.h, _ptr(d_scores), T, n, int(bool(has_blank)), ab,
+                                           _ptr(d_labels), _ptr(d_seq), _ptr(d_len)))
+
+    def basecall_chunks_dev(self, d_signal, n, alphabet, d_seq, d_len):
+        self._check(self.lib.xb_basecall_chunks_dev(self.h, _ptr(d_signal), n, "".join(alphabet).encode(),
+                                                    _ptr(d_seq), _ptr(d_len)))
+
+    def synchronize(self):
+        self._check(self.lib.xb_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self._check(self.lib.xb_set_profiling(self.h, int(bool(on))))
+
+    def reset_stage_times(self):
+        self._check(self.lib.xb_reset_stage_times(self.h))
+
+    def stage_times(self):
+        ms = (C.c_float * 5)()
+        ln = (C.c_int64 * 5)()
+        self._check(self.lib.xb_get_stage_times(self.h, ms, ln))
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(XB_STAGE_NAMES)}

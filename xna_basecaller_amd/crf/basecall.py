@@ -1,0 +1,110 @@
+"""
+CRF basecalling pipeline (ub-bonito/bonito/crf/basecall.py): chunk -> batch -> compute_scores ->
+unbatch -> stitch -> strings, as five generator stages on background threads with bounded queues
+(bonito/multiprocessing.py:20-24,92-122), strict FIFO order.
+"""
+import queue
+from threading import Thread
+
+import numpy as np
+
+from ..util import chunk, stitch, batchify, unbatchify
+
+
+class _ThreadIterator(Thread):
+    """Run an iterator on a background thread behind a bounded queue (exceptions are re-raised)."""
+
+    def __init__(self, iterator, maxsize=1):
+        super().__init__(daemon=True)
+        self.iterator = iterator
+        self.queue = queue.Queue(maxsize)
+
+    def __iter__(self):
+        self.start()
+        while True:
+            item = self.queue.get()
+            if item is StopIteration:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def run(self):
+        try:
+            for item in self.iterator:
+                self.queue.put(item)
+            self.queue.put(StopIteration)
+        except BaseException as e:  # propagate to the consumer instead of hanging it
+            self.queue.put(e)
+
+
+def thread_iter(iterator, maxsize=1):
+    return iter(_ThreadIterator(iterator, maxsize=maxsize))
+
+
+def stitch_results(results, length, size, overlap, stride, reverse=False):
+    """crf/basecall.py:15-24"""
+    if isinstance(results, dict):
+        return {k: stitch_results(v, length, size, overlap, stride, reverse=reverse) for k, v in results.items()}
+    return stitch(results, size, overlap, length, stride, reverse=reverse)
+
+
+def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0,
+                   reverse=False):
+    """
+    crf/basecall.py:27-82, Viterbi branch (the only one reachable for XNA alphabets): (n,1,L) batch ->
+    {'sequence': int8 (n,T) left-packed ASCII, 'qstring': int8 (n,T) of 'O', 'moves': bool (n,T) all False}.
+    One fused device call; the per-character Python loops of the reference are gone.
+    """
+    if not model.encoder[-1].expand_blanks:
+        raise NotImplementedError("koi beam search (expand_blanks=False) is not part of the MI355X path")
+    if reverse:
+        scores = model.seqdist.reverse_complement(model(batch))
+        ctx = model.context(np.asarray(batch).shape[-1], scores.shape[1])
+        sequence, _ = ctx.decode(scores, model.alphabet)
+    else:
+        sequence, _ = model.basecall_chunks(batch)
+    qstring = np.where(sequence != 0, np.int8(ord("O")), np.int8(0)).astype(np.int8)
+    return {
+        "qstring": qstring,
+        "sequence": sequence,
+        "moves": np.zeros(sequence.shape, dtype=bool),
+    }
+
+
+def to_str(x, encoding="ascii"):
+    """koi.decode.to_str: int8 array -> str without the zero padding."""
+    x = np.asarray(x)
+    return x[x != 0].astype(np.uint8).tobytes().decode(encoding)
+
+
+def apply_stride_to_moves(model, attrs):
+    """crf/basecall.py:85-93"""
+    moves = np.array(attrs["moves"], dtype=bool)
+    sig_move = np.full(moves.size * model.stride, False)
+    sig_move[np.where(moves)[0] * model.stride] = True
+    return {
+        "qstring": to_str(attrs["qstring"]),
+        "sequence": to_str(attrs["sequence"]),
+        "sig_move": sig_move,
+    }
+
+
+def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False):
+    """Basecall `reads` (objects with .signal); yields (read, {'sequence','qstring','sig_move'}) in input order."""
+    chunks = thread_iter(
+        ((read, 0, len(read.signal)), chunk(np.asarray(read.signal, dtype=np.float32), chunksize, overlap))
+        for read in reads
+    )
+    batches = thread_iter(batchify(chunks, batchsize=batchsize))
+    scores = thread_iter(
+        (key, compute_scores(model, batch, reverse=reverse)) for key, batch in batches
+    )
+    results = thread_iter(
+        (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
+        for ((read, start, end), sc) in unbatchify(scores)
+    )
+    return thread_iter(
+        (read, apply_stride_to_moves(model, attrs))
+        for read, attrs in results
+    )

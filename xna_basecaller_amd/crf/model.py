@@ -1,0 +1,215 @@
+"""
+CTC-CRF model with the reference's plugin interface (ub-bonito/bonito/crf/model.py:24-237,
+ub-bonito/bonito/nn.py): `Model(config)` exposes .encoder (indexable; [-1].expand_blanks /
+.blank_score), .seqdist (.n_base .alphabet .state_len .idx .reverse_complement), .stride,
+.alphabet, .config, state_dict()/load_state_dict()/half()/eval()/to()/parameters(),
+`model(batch) -> scores (T,N,C)` and `decode_batch(scores) -> list[str]`.
+
+torch is used ONLY as the checkpoint container (parameter names/shapes identical to the
+reference so that util.load_model/match_names work unchanged).  No torch op runs in forward or
+decode: both call the hand-written HIP kernels through the C ABI (include/xna_basecaller.h).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class CTC_CRF:
+    """State/edge bookkeeping of the CRF (crf/model.py:24-46,78-100); arithmetic is on the GPU."""
+
+    def __init__(self, state_len, alphabet):
+        self.alphabet = alphabet
+        self.state_len = state_len
+        self.n_base = len(alphabet[1:])
+        nb, S = self.n_base, self.n_base ** state_len
+        idx = np.empty((S, nb + 1), dtype=np.int32)
+        idx[:, 0] = np.arange(S)
+        # in-edge k >= 1 of state j comes from the state that had base k-1 in front of j's first sl-1 bases
+        idx[:, 1:] = (np.arange(nb)[None, :] * nb ** (state_len - 1) + (np.arange(S) // nb)[:, None])
+        self.idx = torch.from_numpy(idx)
+
+    def n_score(self):
+        return len(self.alphabet) * self.n_base ** self.state_len
+
+    def path_to_str(self, path):
+        alphabet = np.frombuffer("".join(self.alphabet).encode(), dtype="u1")
+        path = np.asarray(path)
+        return alphabet[path[path != 0]].tobytes().decode()
+
+    def reverse_complement(self, scores):
+        """crf/model.py:78-90 on a host (T,N,C) array: flip time, complement every k-mer index."""
+        scores = np.asarray(scores)
+        T, N, C = scores.shape
+        nb, sl = self.n_base, self.state_len
+        x = scores.reshape(T, N, *([nb] * sl), nb + 1)
+        blanks = x[..., 0].transpose(0, 1, *range(sl + 1, 1, -1)).reshape(T, N, -1, 1)[::-1, :, ::-1]
+        em = x[..., 1:].transpose(0, 1, *range(sl, 1, -1), sl + 2, sl + 1).reshape(T, N, -1, nb)[::-1, :, ::-1, ::-1]
+        return np.ascontiguousarray(np.concatenate([blanks, em], axis=-1).reshape(T, N, -1))
+
+
+class Convolution(torch.nn.Module):
+    """Parameter holder for nn.py:57-84 (keys conv.weight / conv.bias)."""
+
+    def __init__(self, insize, size, winlen, stride=1, padding=0, bias=True, activation=None):
+        super().__init__()
+        if activation != "swish" or not bias:
+            raise NotImplementedError("the MI355X path implements Conv1d + bias + swish (rnn_encoder's form)")
+        self.conv = torch.nn.Conv1d(insize, size, winlen, stride=stride, padding=padding, bias=bias)
+        self.stride = stride
+
+
+class Permute(torch.nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+
+class LSTM(torch.nn.Module):
+    """Parameter holder for nn.py:176-235 (keys rnn.{weight_ih_l0,weight_hh_l0,bias_ih_l0,bias_hh_l0})."""
+
+    def __init__(self, size, insize, bias=True, reverse=False):
+        super().__init__()
+        self.rnn = torch.nn.LSTM(size, insize, bias=bias)
+        self.reverse = reverse
+        with torch.no_grad():
+            self.rnn.bias_hh_l0.zero_()
+        self.rnn.bias_hh_l0.requires_grad = False
+
+
+class LinearCRFEncoder(torch.nn.Module):
+    """Parameter holder for nn.py:87-153 (keys linear.weight / linear.bias)."""
+
+    def __init__(self, insize, n_base, state_len, bias=True, scale=None, activation=None, blank_score=None,
+                 expand_blanks=True, extra_linear=False, drop_rate=0):
+        super().__init__()
+        if extra_linear:
+            raise NotImplementedError("extra_linear is a training-time experiment; not on the MI355X path")
+        if activation != "tanh" or scale is None or blank_score is None:
+            raise NotImplementedError("the MI355X path implements scale*tanh(Wx+b) with a fixed blank_score")
+        self.scale, self.n_base, self.state_len = scale, n_base, state_len
+        self.blank_score, self.expand_blanks = blank_score, expand_blanks
+        self.linear = torch.nn.Linear(insize, n_base ** (state_len + 1), bias=bias)
+
+
+def rnn_encoder(n_base, state_len, insize=1, stride=5, winlen=19, activation="swish", rnn_type="lstm",
+                features=768, scale=5.0, blank_score=None, expand_blanks=True, extra_linear=False, drop_rate=0,
+                drop_rate_bottom=0):
+    """Layer list of crf/model.py:142-160 (inference form: dropout layers are identities and are not built)."""
+    if rnn_type != "lstm" or insize != 1:
+        raise NotImplementedError("only insize=1, rnn_type='lstm' encoders are implemented")
+    return torch.nn.Sequential(
+        Convolution(insize, 4, 5, padding=2, activation=activation),
+        Convolution(4, 16, 5, padding=2, activation=activation),
+        Convolution(16, features, winlen, stride=stride, padding=winlen // 2, activation=activation),
+        Permute([2, 0, 1]),
+        LSTM(features, features, reverse=True), LSTM(features, features),
+        LSTM(features, features, reverse=True), LSTM(features, features),
+        LSTM(features, features, reverse=True),
+        LinearCRFEncoder(features, n_base, state_len, activation="tanh", scale=scale, blank_score=blank_score,
+                         expand_blanks=expand_blanks, extra_linear=extra_linear, drop_rate=drop_rate),
+    )
+
+
+def _device_index(device):
+    if isinstance(device, int):
+        return device
+    s = str(device)
+    if s == "cpu":
+        raise RuntimeError("xna_basecaller_amd has no CPU path: run with --device cuda[:N] on an MI355X "
+                           "(the CPU restatement in oracle/ is test infrastructure only)")
+    return int(s.split(":")[1]) if ":" in s else 0
+
+
+class Model(torch.nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.seqdist = CTC_CRF(state_len=config["global_norm"]["state_len"], alphabet=config["labels"]["labels"])
+        if "type" in config["encoder"]:
+            raise NotImplementedError("new-style (typed) encoder configs are not supported")
+        enc = {k: v for k, v in config["encoder"].items()}
+        self.encoder = rnn_encoder(self.seqdist.n_base, self.seqdist.state_len,
+                                   insize=config["input"]["features"], **enc)
+        self.stride = enc.get("stride", 5)
+        self.alphabet = self.seqdist.alphabet
+        self.config = config
+        self._features = enc.get("features", 768)
+        self._winlen = enc.get("winlen", 19)
+        self._device = 0
+        self._ctx = None
+        self._ctx_key = None
+        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16}[
+            os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "f16x3"))]
+
+    # ---- torch.nn.Module surface used by load_model -------------------------------------
+    def to(self, device=None, *args, **kwargs):
+        if device is not None and not isinstance(device, torch.dtype):
+            self._device = _device_index(device)
+            self._drop_context()
+        return self
+
+    def half(self):
+        return self          # arithmetic is fixed by `precision`; the checkpoint stays fp32
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._drop_context()
+        return out
+
+    def _drop_context(self):
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx, self._ctx_key = None, None
+
+    # ---- device context -------------------------------------------------------------------
+    def context(self, chunk_len, batch):
+        """The xb_ctx for this chunk length; rebuilt when the geometry grows."""
+        key = (self._device, int(chunk_len), self.precision)
+        if self._ctx is None or self._ctx_key != key or batch > self._ctx.max_batch:
+            self._drop_context()
+            last = self.encoder[-1]
+            ctx = _lib.Context(self._device, self.seqdist.n_base, self.seqdist.state_len, self._features,
+                               self._winlen, self.stride, float(last.scale), float(last.blank_score),
+                               int(chunk_len), int(batch), precision=self.precision)
+            sd = {k: v.detach().to(torch.float32).cpu().numpy() for k, v in self.state_dict().items()}
+            ctx.load_state_dict(sd)
+            self._ctx, self._ctx_key = ctx, key
+        return self._ctx
+
+    # ---- operators ----------------------------------------------------------------------
+    @staticmethod
+    def _as_signal(x):
+        if hasattr(x, "detach"):
+            x = x.detach().to(torch.float32).cpu().numpy()
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim == 3:
+            x = x[:, 0, :]
+        return np.ascontiguousarray(x)
+
+    def forward(self, x):
+        """(N,1,L) signal -> (T,N,C) fp32 scores on the host (crf/model.py:212-213)."""
+        sig = self._as_signal(x)
+        ctx = self.context(sig.shape[1], sig.shape[0])
+        return ctx.encode(sig, expand_blanks=self.encoder[-1].expand_blanks)
+
+    def decode_batch(self, x):
+        """(T,N,C) scores -> list of called strings (crf/model.py:215-218)."""
+        if hasattr(x, "detach"):
+            x = x.detach().to(torch.float32).cpu().numpy()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        T, N, _ = x.shape
+        ctx = self.context(T * self.stride, N)
+        seq, lens = ctx.decode(x, self.alphabet)
+        return [seq[i, :lens[i]].tobytes().decode() for i in range(N)]
+
+    def decode(self, x):
+        return self.decode_batch(np.asarray(x)[:, None, :])[0]
+
+    def basecall_chunks(self, batch):
+        """Fused encode + decode of a (N,1,L) batch -> (seq (N,T) int8 left-packed ASCII, lens (N,))."""
+        sig = self._as_signal(batch)
+        ctx = self.context(sig.shape[1], sig.shape[0])
+        return ctx.basecall_chunks(sig, self.alphabet)

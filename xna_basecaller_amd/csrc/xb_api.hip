@@ -1,0 +1,621 @@
+// xb_api.hip -- C ABI of libxnacall.so (see include/xna_basecaller.h for the contract and the
+// reference call sites each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/xna_basecaller.h"
+#include "xb_internal.h"
+
+using xb::half_t;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct StageEvent {
+    int stage;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct xb_ctx {
+    xb_config cfg{};
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    int T = 0, S = 0, hi = 0, O = 0, kp = 0, ld_nb = 0;
+    bool weights_ready = false;
+    std::map<std::string, std::vector<float>> host_w;
+    std::vector<DevBuf> bufs;
+
+    // weights on device
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
+    half_t *w3_hi = nullptr, *w3_lo = nullptr;
+    half_t *wih_hi[5] = {}, *wih_lo[5] = {}, *whh_hi[5] = {}, *whh_lo[5] = {};
+    float *lbias[5] = {};
+    half_t *wl_hi = nullptr, *wl_lo = nullptr;
+    float *bl = nullptr;
+
+    // activations / workspaces
+    float *d_signal = nullptr;
+    half_t *im_hi = nullptr, *im_lo = nullptr;
+    half_t *x_hi[2] = {}, *x_lo[2] = {};
+    float *gin = nullptr, *c_state = nullptr, *scores = nullptr;
+    float *alpha = nullptr, *beta = nullptr, *bmax = nullptr;
+    int8_t *labels = nullptr, *seq = nullptr;
+    int32_t *seq_len = nullptr;
+    unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
+    unsigned *error = nullptr;
+    int lstm_mode = 0;
+
+    bool profiling = false;
+    std::vector<StageEvent> events;
+    float stage_ms[XB_STAGE_COUNT] = {};
+    int64_t stage_launches[XB_STAGE_COUNT] = {};
+};
+
+namespace {
+
+int fail(const xb_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define XB_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? XB_ERR_NOMEM : XB_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int64_t ipow(int64_t b, int e) { int64_t r = 1; while (e-- > 0) r *= b; return r; }
+
+template <typename Tp>
+int dev_alloc(xb_ctx *ctx, Tp **out, size_t count)
+{
+    void *p = nullptr;
+    const size_t bytes = (count * sizeof(Tp) + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail(ctx, XB_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    ctx->bufs.push_back({p, bytes});
+    *out = reinterpret_cast<Tp *>(p);
+    return XB_OK;
+}
+
+struct StageScope {
+    xb_ctx *c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(xb_ctx *ctx, int st, int launches) : c(ctx), stage(st)
+    {
+        c->stage_launches[st] += launches;
+        if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            hipEventRecord(a, c->stream);
+    }
+    ~StageScope()
+    {
+        if (a && b) {
+            hipEventRecord(b, c->stream);
+            c->events.push_back({stage, a, b});
+        }
+    }
+};
+
+int collect_events(xb_ctx *ctx)
+{
+    for (auto &ev : ctx->events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
+            ctx->stage_ms[ev.stage] += ms;
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    ctx->events.clear();
+    return XB_OK;
+}
+
+// expected element count of each state-dict tensor
+int64_t expected_size(const xb_ctx *c, const std::string &name)
+{
+    const int64_t F = c->cfg.features, W = c->cfg.winlen;
+    if (name == "encoder.0.conv.weight") return 4 * 1 * 5;
+    if (name == "encoder.0.conv.bias") return 4;
+    if (name == "encoder.1.conv.weight") return 16 * 4 * 5;
+    if (name == "encoder.1.conv.bias") return 16;
+    if (name == "encoder.2.conv.weight") return F * 16 * W;
+    if (name == "encoder.2.conv.bias") return F;
+    for (int l = 4; l <= 8; ++l) {
+        const std::string pre = "encoder." + std::to_string(l) + ".rnn.";
+        if (name == pre + "weight_ih_l0" || name == pre + "weight_hh_l0") return 4 * F * F;
+        if (name == pre + "bias_ih_l0" || name == pre + "bias_hh_l0") return 4 * F;
+    }
+    if (name == "encoder.9.linear.weight") return (int64_t)c->O * F;
+    if (name == "encoder.9.linear.bias") return c->O;
+    return -1;
+}
+
+void split_rows(const float *src, int rows, int cols, int ld, std::vector<half_t> &hi, std::vector<half_t> &lo)
+{
+    hi.assign((size_t)rows * ld, (half_t)0.0f);
+    lo.assign((size_t)rows * ld, (half_t)0.0f);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const float v = src[(size_t)r * cols + c];
+            const half_t h = (half_t)v;
+            hi[(size_t)r * ld + c] = h;
+            lo[(size_t)r * ld + c] = (half_t)(v - (float)h);
+        }
+}
+
+template <typename Tp>
+int upload(xb_ctx *ctx, Tp **dst, const std::vector<Tp> &src)
+{
+    int rc = dev_alloc(ctx, dst, src.size());
+    if (rc) return rc;
+    XB_HIP(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    return XB_OK;
+}
+
+int check_ready(xb_ctx *ctx, int n)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (!ctx->weights_ready) return fail(ctx, XB_ERR_STATE, "weights not loaded: call xb_load_weights for all 28 tensors, then xb_weights_ready");
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    return XB_OK;
+}
+
+int check_device_error(xb_ctx *ctx)
+{
+    unsigned e = 0;
+    XB_HIP(ctx, hipMemcpyAsync(&e, ctx->error, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (e != 0) {
+        hipMemsetAsync(ctx->error, 0, sizeof(unsigned), ctx->stream);
+        return fail(ctx, XB_ERR_DEVICE, "LSTM inter-workgroup sync timed out (persistent kernel was not fully resident?)");
+    }
+    return XB_OK;
+}
+
+// ---- encoder orchestration --------------------------------------------------------------
+int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const half_t *xin_lo, half_t *xout_hi,
+                   half_t *xout_lo)
+{
+    const int F = ctx->cfg.features, T = ctx->T;
+    const int nsplit = ctx->cfg.precision == XB_PREC_F16 ? 1 : 3;
+    {
+        StageScope sc(ctx, XB_STAGE_LSTM_IN, 1);
+        xb::GemmParams g{};
+        g.a_hi = xin_hi; g.a_lo = xin_lo; g.b_hi = ctx->wih_hi[layer]; g.b_lo = ctx->wih_lo[layer];
+        g.M = T * n; g.Nn = 4 * F; g.K = F; g.lda = F; g.ldb = F;
+        g.bias = ctx->lbias[layer]; g.out_f32 = ctx->gin; g.ldc = 4 * F; g.nsplit = nsplit;
+        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, ctx->stream));
+    }
+    const int members = xb::lstm_members(F), bn = xb::lstm_group_chunks();
+    int mode = ctx->lstm_mode;
+    const int gmax = ctx->cu_count / members;
+    if (mode == 0) mode = gmax >= 1 ? 2 : 1;
+    if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
+    XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));
+    xb::LstmParams p{};
+    p.gin = ctx->gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
+    p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state;
+    p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
+    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = nsplit;
+    if (mode == 2) {
+        const int slab = gmax > 64 ? 64 * bn : gmax * bn;
+        int launches = 0;
+        for (int n0 = 0; n0 < n; n0 += slab) ++launches;
+        StageScope sc(ctx, XB_STAGE_LSTM_REC, launches);
+        for (int n0 = 0; n0 < n; n0 += slab) {
+            p.n0 = n0; p.nslab = (n - n0) < slab ? (n - n0) : slab;
+            p.s_begin = 0; p.s_end = T; p.persistent = 1;
+            XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
+            XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
+        }
+    } else {
+        StageScope sc(ctx, XB_STAGE_LSTM_REC, T);
+        p.n0 = 0; p.nslab = n; p.persistent = 0;
+        for (int s = 0; s < T; ++s) {
+            p.s_begin = s; p.s_end = s + 1;
+            XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
+        }
+    }
+    return XB_OK;
+}
+
+// scores_out: (T, n, ldc) with ldc given; expand selects the blank-column layout
+int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *scores_out, int ldc)
+{
+    const xb_config &c = ctx->cfg;
+    const int F = c.features, T = ctx->T;
+    const int nsplit = c.precision == XB_PREC_F16 ? 1 : 3;
+    {
+        StageScope sc(ctx, XB_STAGE_CONV, 2);
+        xb::ConvFrontParams cf{};
+        cf.signal = d_signal; cf.N = n; cf.L = c.chunk_len; cf.T = T; cf.winlen = c.winlen; cf.stride = c.stride;
+        cf.kp = ctx->kp; cf.w1 = ctx->w1; cf.b1 = ctx->b1; cf.w2 = ctx->w2; cf.b2 = ctx->b2;
+        cf.a_hi = ctx->im_hi; cf.a_lo = ctx->im_lo;
+        XB_HIP(ctx, xb::launch_conv_front(cf, ctx->stream));
+        xb::GemmParams g{};
+        g.a_hi = ctx->im_hi; g.a_lo = ctx->im_lo; g.b_hi = ctx->w3_hi; g.b_lo = ctx->w3_lo;
+        g.M = T * n; g.Nn = F; g.K = ctx->kp; g.lda = ctx->kp; g.ldb = ctx->kp;
+        g.bias = ctx->b3; g.out_hi = ctx->x_hi[0]; g.out_lo = ctx->x_lo[0]; g.ldc = F; g.nsplit = nsplit;
+        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_SILU_SPLIT, ctx->stream));
+    }
+    int cur = 0;
+    for (int l = 0; l < 5; ++l) {
+        int rc = run_lstm_layer(ctx, l, n, ctx->x_hi[cur], ctx->x_lo[cur], ctx->x_hi[cur ^ 1], ctx->x_lo[cur ^ 1]);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    {
+        StageScope sc(ctx, XB_STAGE_LINEAR, 1);
+        xb::GemmParams g{};
+        g.a_hi = ctx->x_hi[cur]; g.a_lo = ctx->x_lo[cur]; g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo;
+        g.M = T * n; g.Nn = ctx->O; g.K = F; g.lda = F; g.ldb = F;
+        g.bias = ctx->bl; g.out_f32 = scores_out; g.ldc = ldc; g.scale = c.scale; g.nb = c.n_base;
+        g.expand = expand; g.blank = c.blank_score; g.nsplit = nsplit;
+        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, ctx->stream));
+    }
+    return XB_OK;
+}
+
+int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, int ld, const char *alphabet,
+               int8_t *d_labels, int8_t *d_seq, int32_t *d_len)
+{
+    const xb_config &c = ctx->cfg;
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    xb::DecodeParams p{};
+    p.scores = d_scores; p.T = T; p.N = n; p.S = ctx->S; p.hi = ctx->hi; p.nb = c.n_base;
+    p.cin = has_blank ? ctx->S * (c.n_base + 1) : ctx->S * c.n_base;
+    p.ld = ld; p.has_blank = has_blank; p.blank = c.blank_score;
+    p.alpha = ctx->alpha; p.beta = ctx->beta; p.bmax = ctx->bmax; p.logz = nullptr;
+    p.labels = d_labels; p.seq = d_seq; p.seq_len = d_len;
+    memset(p.alphabet, 0, sizeof p.alphabet);
+    if (alphabet) {
+        if ((int)strlen(alphabet) < c.n_base + 1) return fail(ctx, XB_ERR_INVALID, "alphabet needs %d symbols", c.n_base + 1);
+        memcpy(p.alphabet, alphabet, (size_t)c.n_base + 1);
+    } else if (d_seq) {
+        return fail(ctx, XB_ERR_INVALID, "alphabet is required when seq is requested");
+    }
+    StageScope sc(ctx, XB_STAGE_DECODE, 1);
+    hipError_t e = xb::launch_crf_decode(p, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? XB_ERR_INVALID : XB_ERR_HIP, "crf decode launch failed: %s", hipGetErrorString(e));
+    return XB_OK;
+}
+
+}  // namespace
+
+// ===========================================================================================
+extern "C" {
+
+XB_API const char *xb_version(void) { return "xnacall 0.1.0 (gfx950)"; }
+
+XB_API int xb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+XB_API const char *xb_last_error(const xb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
+{
+    if (!out || !cfg) return fail(nullptr, XB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n_base < 4 || cfg->n_base > 6) return fail(nullptr, XB_ERR_INVALID, "n_base %d not in {4,5,6}", cfg->n_base);
+    if (cfg->state_len < 2 || cfg->state_len > 5) return fail(nullptr, XB_ERR_INVALID, "state_len %d not in [2,5]", cfg->state_len);
+    const int64_t S = ipow(cfg->n_base, cfg->state_len);
+    if (S > 1024) return fail(nullptr, XB_ERR_INVALID, "n_base^state_len = %lld exceeds 1024 states", (long long)S);
+    if (!xb::lstm_supported_features(cfg->features))
+        return fail(nullptr, XB_ERR_INVALID, "features %d unsupported (32,64,96,128,256,384,512,768)", cfg->features);
+    if (cfg->winlen < 1 || cfg->winlen > 31 || cfg->winlen % 2 == 0 || cfg->stride < 1 || cfg->stride > 8)
+        return fail(nullptr, XB_ERR_INVALID, "winlen %d / stride %d unsupported", cfg->winlen, cfg->stride);
+    if (cfg->chunk_len < cfg->stride || cfg->max_batch < 1) return fail(nullptr, XB_ERR_INVALID, "bad chunk_len/max_batch");
+    if (cfg->precision != XB_PREC_F16X3 && cfg->precision != XB_PREC_F16) return fail(nullptr, XB_ERR_INVALID, "bad precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, XB_ERR_NO_GPU, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, XB_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+
+    xb_ctx *ctx = new (std::nothrow) xb_ctx();
+    if (!ctx) return fail(nullptr, XB_ERR_NOMEM, "out of host memory");
+    ctx->cfg = *cfg;
+    ctx->device = device;
+    const int pad = cfg->winlen / 2;
+    ctx->T = (cfg->chunk_len + 2 * pad - cfg->winlen) / cfg->stride + 1;
+    ctx->S = (int)S;
+    ctx->hi = (int)ipow(cfg->n_base, cfg->state_len - 1);
+    ctx->O = (int)(S * cfg->n_base);
+    ctx->kp = (16 * cfg->winlen + 31) & ~31;
+    ctx->ld_nb = (ctx->O + 3) & ~3;
+    ctx->lstm_mode = cfg->lstm_mode;
+    if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
+
+#define XB_CREATE_HIP(call)                                                                   \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            int rc_ = fail(nullptr, XB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            xb_ctx_destroy(ctx);                                                              \
+            return rc_;                                                                       \
+        }                                                                                     \
+    } while (0)
+    XB_CREATE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    XB_CREATE_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, XB_ERR_NO_GPU, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+        xb_ctx_destroy(ctx);
+        return rc;
+    }
+    ctx->cu_count = prop.multiProcessorCount;
+    XB_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+
+    const size_t N = cfg->max_batch, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
+    const size_t Cb = (size_t)S * (cfg->n_base + 1);
+    const size_t Cmax = Cb > (size_t)ctx->ld_nb ? Cb : (size_t)ctx->ld_nb;
+    int rc = XB_OK;
+    rc = rc ? rc : dev_alloc(ctx, &ctx->d_signal, N * L);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->im_hi, T * N * ctx->kp);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->im_lo, T * N * ctx->kp);
+    for (int i = 0; i < 2 && !rc; ++i) {
+        rc = rc ? rc : dev_alloc(ctx, &ctx->x_hi[i], T * N * F);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->x_lo[i], T * N * F);
+    }
+    rc = rc ? rc : dev_alloc(ctx, &ctx->gin, T * N * 4 * F);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->sync, (size_t)64 * 32 + 32);
+    if (rc) {
+        g_create_error = ctx->err;
+        xb_ctx_destroy(ctx);
+        return rc;
+    }
+    ctx->error = ctx->sync + 64 * 32;
+    XB_CREATE_HIP(hipMemset(ctx->sync, 0, sizeof(unsigned) * (64 * 32 + 32)));
+#undef XB_CREATE_HIP
+    *out = ctx;
+    return XB_OK;
+}
+
+XB_API void xb_ctx_destroy(xb_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto &b : ctx->bufs) hipFree(b.p);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+XB_API int xb_load_weights(xb_ctx *ctx, const char *name, const float *host, int64_t n)
+{
+    if (!ctx || !name || !host) return fail(ctx, XB_ERR_INVALID, "null argument");
+    const int64_t want = expected_size(ctx, name);
+    if (want < 0) return fail(ctx, XB_ERR_INVALID, "unknown state-dict key '%s'", name);
+    if (want != n) return fail(ctx, XB_ERR_INVALID, "'%s': got %lld elements, config implies %lld", name, (long long)n, (long long)want);
+    ctx->host_w[name].assign(host, host + n);
+    ctx->weights_ready = false;
+    return XB_OK;
+}
+
+XB_API int xb_weights_ready(xb_ctx *ctx)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    const int F = ctx->cfg.features, W = ctx->cfg.winlen;
+    auto need = [&](const std::string &k) -> const std::vector<float> * {
+        auto it = ctx->host_w.find(k);
+        return it == ctx->host_w.end() ? nullptr : &it->second;
+    };
+    std::vector<std::string> keys = {"encoder.0.conv.weight", "encoder.0.conv.bias", "encoder.1.conv.weight",
+                                     "encoder.1.conv.bias", "encoder.2.conv.weight", "encoder.2.conv.bias",
+                                     "encoder.9.linear.weight", "encoder.9.linear.bias"};
+    for (int l = 4; l <= 8; ++l)
+        for (const char *s : {"weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"})
+            keys.push_back("encoder." + std::to_string(l) + ".rnn." + s);
+    for (auto &k : keys)
+        if (!need(k)) return fail(ctx, XB_ERR_STATE, "missing tensor '%s'", k.c_str());
+
+    int rc;
+    if ((rc = upload(ctx, &ctx->w1, *need("encoder.0.conv.weight")))) return rc;
+    if ((rc = upload(ctx, &ctx->b1, *need("encoder.0.conv.bias")))) return rc;
+    if ((rc = upload(ctx, &ctx->w2, *need("encoder.1.conv.weight")))) return rc;
+    if ((rc = upload(ctx, &ctx->b2, *need("encoder.1.conv.bias")))) return rc;
+    if ((rc = upload(ctx, &ctx->b3, *need("encoder.2.conv.bias")))) return rc;
+    std::vector<half_t> hi, lo;
+    split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo);
+    if ((rc = upload(ctx, &ctx->w3_hi, hi))) return rc;
+    if ((rc = upload(ctx, &ctx->w3_lo, lo))) return rc;
+    for (int l = 0; l < 5; ++l) {
+        const std::string pre = "encoder." + std::to_string(4 + l) + ".rnn.";
+        const float *wih = need(pre + "weight_ih_l0")->data(), *whh = need(pre + "weight_hh_l0")->data();
+        const float *bih = need(pre + "bias_ih_l0")->data(), *bhh = need(pre + "bias_hh_l0")->data();
+        // gate-interleaved row order: row' = unit*4 + gate  <-  row = gate*F + unit  (gates i,f,g,o)
+        std::vector<float> wi((size_t)4 * F * F), wh((size_t)4 * F * F), bb((size_t)4 * F);
+        for (int u = 0; u < F; ++u)
+            for (int q = 0; q < 4; ++q) {
+                memcpy(&wi[((size_t)u * 4 + q) * F], &wih[((size_t)q * F + u) * F], sizeof(float) * F);
+                memcpy(&wh[((size_t)u * 4 + q) * F], &whh[((size_t)q * F + u) * F], sizeof(float) * F);
+                bb[(size_t)u * 4 + q] = bih[(size_t)q * F + u] + bhh[(size_t)q * F + u];
+            }
+        split_rows(wi.data(), 4 * F, F, F, hi, lo);
+        if ((rc = upload(ctx, &ctx->wih_hi[l], hi))) return rc;
+        if ((rc = upload(ctx, &ctx->wih_lo[l], lo))) return rc;
+        split_rows(wh.data(), 4 * F, F, F, hi, lo);
+        if ((rc = upload(ctx, &ctx->whh_hi[l], hi))) return rc;
+        if ((rc = upload(ctx, &ctx->whh_lo[l], lo))) return rc;
+        if ((rc = upload(ctx, &ctx->lbias[l], bb))) return rc;
+    }
+    split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo);
+    if ((rc = upload(ctx, &ctx->wl_hi, hi))) return rc;
+    if ((rc = upload(ctx, &ctx->wl_lo, lo))) return rc;
+    if ((rc = upload(ctx, &ctx->bl, *need("encoder.9.linear.bias")))) return rc;
+    ctx->host_w.clear();
+    ctx->weights_ready = true;
+    return XB_OK;
+}
+
+XB_API int xb_synchronize(xb_ctx *ctx)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_device_error(ctx);
+}
+
+XB_API int xb_encode_dev(xb_ctx *ctx, const float *d_signal, int n, int expand_blanks, float *d_scores)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (!d_signal || !d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    const int ldc = expand_blanks ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    return run_encoder(ctx, d_signal, n, expand_blanks ? 1 : 0, d_scores, ldc);
+}
+
+XB_API int xb_encode(xb_ctx *ctx, const float *signal, int n, int expand_blanks, float *scores)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (!signal || !scores) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    XB_HIP(ctx, hipMemcpyAsync(ctx->d_signal, signal, sizeof(float) * (size_t)n * ctx->cfg.chunk_len,
+                               hipMemcpyHostToDevice, ctx->stream));
+    const int ldc = expand_blanks ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    rc = run_encoder(ctx, ctx->d_signal, n, expand_blanks ? 1 : 0, ctx->scores, ldc);
+    if (rc) return rc;
+    XB_HIP(ctx, hipMemcpyAsync(scores, ctx->scores, sizeof(float) * (size_t)ctx->T * n * ldc, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, const char *alphabet,
+                         int8_t *d_labels, int8_t *d_seq, int32_t *d_seq_len)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, alphabet, d_labels, d_seq, d_seq_len);
+}
+
+XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, const char *alphabet,
+                     int8_t *labels, int8_t *seq, int32_t *seq_len)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!scores) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_decode(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, alphabet, ctx->labels, seq ? ctx->seq : nullptr,
+                        ctx->seq_len);
+    if (rc) return rc;
+    if (labels) XB_HIP(ctx, hipMemcpyAsync(labels, ctx->labels, (size_t)n * T, hipMemcpyDeviceToHost, ctx->stream));
+    if (seq) XB_HIP(ctx, hipMemcpyAsync(seq, ctx->seq, (size_t)n * T, hipMemcpyDeviceToHost, ctx->stream));
+    if (seq_len) XB_HIP(ctx, hipMemcpyAsync(seq_len, ctx->seq_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet, int8_t *d_seq,
+                                  int32_t *d_seq_len)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (!d_signal || !d_seq || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    rc = run_encoder(ctx, d_signal, n, 0, ctx->scores, ctx->ld_nb);
+    if (rc) return rc;
+    return run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len);
+}
+
+XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet, int8_t *seq,
+                              int32_t *seq_len)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (!signal || !seq || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    XB_HIP(ctx, hipMemcpyAsync(ctx->d_signal, signal, sizeof(float) * (size_t)n * ctx->cfg.chunk_len,
+                               hipMemcpyHostToDevice, ctx->stream));
+    rc = xb_basecall_chunks_dev(ctx, ctx->d_signal, n, alphabet, ctx->seq, ctx->seq_len);
+    if (rc) return rc;
+    XB_HIP(ctx, hipMemcpyAsync(seq, ctx->seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, ctx->stream));
+    if (seq_len) XB_HIP(ctx, hipMemcpyAsync(seq_len, ctx->seq_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_set_profiling(xb_ctx *ctx, int on)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return XB_OK;
+}
+
+XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t launches[XB_STAGE_COUNT])
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
+    for (int i = 0; i < XB_STAGE_COUNT; ++i) {
+        if (ms) ms[i] = ctx->stage_ms[i];
+        if (launches) launches[i] = ctx->stage_launches[i];
+    }
+    return XB_OK;
+}
+
+XB_API int xb_reset_stage_times(xb_ctx *ctx)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
+    for (int i = 0; i < XB_STAGE_COUNT; ++i) { ctx->stage_ms[i] = 0.f; ctx->stage_launches[i] = 0; }
+    return XB_OK;
+}
+
+XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_noblank)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (T) *T = ctx->T;
+    if (S) *S = ctx->S;
+    if (C_blank) *C_blank = ctx->S * (ctx->cfg.n_base + 1);
+    if (C_noblank) *C_noblank = ctx->O;
+    return XB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,481 @@
+// xb_decode.hip -- CRF posterior + max-plus decode for gfx950 (MI355X).
+//
+// Replaces SeqdistModel.decode_batch (ub-bonito/bonito/crf/model.py:215-218) =
+//   seqdist posteriors (Log semiring fwd/bwd scans, crf/model.py:41-46)
+//   -> +1e-8 -> log -> seqdist posteriors with the Max semiring -> argmax % (n_base+1)
+//   (crf/model.py:92-95), then path_to_str (crf/model.py:97-100) and the left-pack of
+//   compute_scores (crf/basecall.py:60-67).
+//
+// One workgroup per chunk, one thread per CRF state; the state vectors (alpha, beta, max-plus
+// alpha/beta) live in LDS and are exchanged once per time step behind a single barrier.
+// Scores stream from HBM through a register ring (D steps ahead) in 4/8/16-byte coalesced
+// loads, are staged in LDS and consumed by state.  Three sweeps over the scores:
+//   1. Log forward           (write alpha)
+//   2. Log backward fused with Max backward (read alpha; write beta, bmax)
+//   3. Max forward with recomputed log-posterior + per-step arg-max of the max-marginals
+//      (read alpha, beta, bmax), then pack.
+//
+// Floating-point contract (shared by specification with oracle/xna_oracle.c, written
+// independently): IEEE binary32, no contraction (this file is built with -ffp-contract=off),
+// fma only where __builtin_fmaf is written, exp/log are the fixed polynomials below, logsumexp
+// is max / ordered sum of exp / log, ties resolve to the lowest flat edge index.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xb_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ float xb_expf(float x)
+{
+    const bool tiny = x < -87.0f;
+    x = x > 88.0f ? 88.0f : x;
+    x = tiny ? 0.0f : x;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    const int ni = (int)n;
+    const float s = bits2f((uint32_t)(ni + 127) << 23);
+    const float v = y * s;
+    return tiny ? 0.0f : v;
+}
+
+__device__ __forceinline__ float xb_logf(float x)
+{
+    const uint32_t ix = f2bits(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = bits2f((ix & 0x007fffffu) | 0x3f800000u);
+    const bool big = m > 1.41421356237309505f;
+    m = big ? m * 0.5f : m;
+    e = big ? e + 1 : e;
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, f, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, f, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, f, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, f, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, f, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, f, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, f, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    const float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+__device__ __forceinline__ float maxf(float a, float b) { return b > a ? b : a; }
+
+template <int VW> struct VecT;
+template <> struct VecT<1> { using type = float; };
+// native clang vectors (HIP's float2/float4 wrapper structs defeat scalar replacement in arrays)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <> struct VecT<2> { using type = f32x2; };
+template <> struct VecT<4> { using type = f32x4; };
+
+// Score row of one (t, chunk): `cin` floats at row pointer; staged into LDS by all BS threads in
+// groups of VW floats.  NR = groups per thread.
+template <int VW, int NR, int BS>
+struct ScoreRing {
+    using V = typename VecT<VW>::type;
+    V r[NR];
+    __device__ __forceinline__ void load(const float *row, int cin, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            // out-of-range groups re-read group 0 (always valid) instead of predicating the load:
+            // keeps the ring in registers; the LDS store below is what is guarded
+            const int g = (tid + BS * i) * VW;
+            r[i] = *reinterpret_cast<const V *>(row + (g < cin ? g : 0));
+        }
+    }
+    __device__ __forceinline__ void store(float *lds, int cin, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int g = (tid + BS * i) * VW;
+            if (g < cin) *reinterpret_cast<V *>(lds + g) = r[i];
+        }
+    }
+};
+
+constexpr int DEPTH = 4;   // time steps of scores in flight per workgroup
+
+// M[j][k] from the staged row: with the blank column present it is lds[j*E+k]; otherwise column 0
+// is the constant blank and column k>=1 is lds[j*NB + k-1].
+template <int NB, bool HB>
+__device__ __forceinline__ float score_at(const float *lds, int j, int k, float blank)
+{
+    constexpr int E = NB + 1;
+    if (HB) return lds[j * E + k];
+    return k == 0 ? blank : lds[j * NB + k - 1];
+}
+
+template <int NB, int BS, int VW, bool HB>
+__global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
+{
+    constexpr int E = NB + 1;
+    constexpr int NR = (E + VW - 1) / VW;           // BS*NR*VW >= S*E >= cin
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const bool act = tid < S;
+    const int cpad = (cin + 3) & ~3;
+
+    float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]
+    float *sA = sM + 2 * cpad;                                    // [2][S]  alpha / beta
+    float *sX = sA + 2 * S;                                       // [2][S]  max-plus alpha / beta
+    float *sG = sX + 2 * S;                                       // [2][S]  gathered alpha row (sweep 3)
+    float *sRv = sG + 2 * S;                                      // [2][BS/64] arg-max partials
+    int *sRi = reinterpret_cast<int *>(sRv + 2 * (BS / 64));      // [2][BS/64]
+    float *sBc = reinterpret_cast<float *>(sRi + 2 * (BS / 64));  // [4] broadcast scratch
+    int8_t *sLab = reinterpret_cast<int8_t *>(sBc + 4);           // [T]
+
+    const float *sc = p.scores + (size_t)n * p.ld;
+    const size_t tstride = (size_t)N * p.ld;
+    float *alpha = p.alpha + (size_t)n * S;
+    float *beta = p.beta + (size_t)n * S;
+    float *bmax = p.bmax + (size_t)n * S;
+    const size_t sstride = (size_t)N * S;
+    const float blank = p.blank;
+
+    ScoreRing<VW, NR, BS> ring[DEPTH];
+
+    // ------------------------------------------------------------------ sweep 1: Log forward
+    if (act) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < T) ring[d].load(sc + (size_t)d * tstride, cin, tid);
+
+    for (int t0 = 0; t0 < T; t0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int t = t0 + d;
+            if (t < T) {
+                float *m = sM + (t & 1) * cpad;
+                ring[d].store(m, cin, tid);
+                if (t + DEPTH < T) ring[d].load(sc + (size_t)(t + DEPTH) * tstride, cin, tid);
+                __syncthreads();
+                if (act) {
+                    const float *a0 = sA + (t & 1) * S;
+                    const int j = tid;
+                    float x[E];
+                    x[0] = score_at<NB, HB>(m, j, 0, blank) + a0[j];
+                    float mx = x[0];
+                    const int jq = j / NB;
+#pragma unroll
+                    for (int k = 1; k < E; ++k) {
+                        x[k] = score_at<NB, HB>(m, j, k, blank) + a0[(k - 1) * hi + jq];
+                        mx = maxf(mx, x[k]);
+                    }
+                    float s = xb_expf(x[0] - mx);
+#pragma unroll
+                    for (int k = 1; k < E; ++k) s += xb_expf(x[k] - mx);
+                    const float v = mx + xb_logf(s);
+                    sA[((t + 1) & 1) * S + j] = v;
+                    alpha[(size_t)(t + 1) * sstride + j] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // logZ = logsumexp_j alpha_T[j], summed in order j = 0..S-1
+    {
+        const float *aT = sA + (T & 1) * S;
+        if (tid == 0) {
+            float mx = aT[0];
+            for (int j = 1; j < S; ++j) mx = maxf(mx, aT[j]);
+            sBc[0] = mx;
+        }
+        __syncthreads();
+        const float mx = sBc[0];
+        if (act) sG[tid] = xb_expf(aT[tid] - mx);
+        __syncthreads();
+        if (tid == 0) {
+            float s = sG[0];
+            for (int j = 1; j < S; ++j) s += sG[j];
+            const float lz = mx + xb_logf(s);
+            sBc[1] = lz;
+            if (p.logz) p.logz[n] = lz;
+        }
+        __syncthreads();
+    }
+    const float logZ = sBc[1];
+
+    // -------------------------------------------- sweep 2: Log backward + Max backward (fused)
+    {
+        float aring[DEPTH];
+        if (act) {
+            sA[(T & 1) * S + tid] = 0.0f;
+            sX[(T & 1) * S + tid] = 0.0f;
+            beta[(size_t)T * sstride + tid] = 0.0f;
+            bmax[(size_t)T * sstride + tid] = 0.0f;
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int t = T - 1 - d;
+            if (t >= 0) {
+                ring[d].load(sc + (size_t)t * tstride, cin, tid);
+                if (act) aring[d] = alpha[(size_t)t * sstride + tid];
+            }
+        }
+        const int i = tid;
+        const int kk = i / hi + 1;
+        const int jb = (i % hi) * NB;
+        for (int s0 = 0; s0 < T; s0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int t = T - 1 - (s0 + d);
+                if (t >= 0) {
+                    float *m = sM + (t & 1) * cpad;
+                    ring[d].store(m, cin, tid);
+                    const float a0 = aring[d];
+                    if (t - DEPTH >= 0) {
+                        ring[d].load(sc + (size_t)(t - DEPTH) * tstride, cin, tid);
+                        if (act) aring[d] = alpha[(size_t)(t - DEPTH) * sstride + tid];
+                    }
+                    __syncthreads();
+                    if (act) {
+                        const float *b1 = sA + ((t + 1) & 1) * S;
+                        const float *m1 = sX + ((t + 1) & 1) * S;
+                        float y[E], q[E], mb[E];
+                        {
+                            const float mv = score_at<NB, HB>(m, i, 0, blank);
+                            const float bj = b1[i];
+                            y[0] = mv + bj;
+                            const float xx = ((a0 + mv) + bj) - logZ;
+                            q[0] = xb_logf(xb_expf(xx) + 1e-8f);
+                            mb[0] = m1[i];
+                        }
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const int j = jb + b;
+                            const float mv = score_at<NB, HB>(m, j, kk, blank);
+                            const float bj = b1[j];
+                            y[b + 1] = mv + bj;
+                            const float xx = ((a0 + mv) + bj) - logZ;
+                            q[b + 1] = xb_logf(xb_expf(xx) + 1e-8f);
+                            mb[b + 1] = m1[j];
+                        }
+                        float mx = y[0];
+#pragma unroll
+                        for (int e = 1; e < E; ++e) mx = maxf(mx, y[e]);
+                        float s = xb_expf(y[0] - mx);
+#pragma unroll
+                        for (int e = 1; e < E; ++e) s += xb_expf(y[e] - mx);
+                        const float bv = mx + xb_logf(s);
+                        float mm = q[0] + mb[0];
+#pragma unroll
+                        for (int e = 1; e < E; ++e) mm = maxf(mm, q[e] + mb[e]);
+                        sA[(t & 1) * S + i] = bv;
+                        sX[(t & 1) * S + i] = mm;
+                        beta[(size_t)t * sstride + i] = bv;
+                        bmax[(size_t)t * sstride + i] = mm;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // --------------------------- sweep 3: Max forward + per-step arg-max of the max-marginals
+    {
+        float aring[DEPTH], bring[DEPTH], mring[DEPTH];
+        if (act) sX[tid] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (d < T) {
+                ring[d].load(sc + (size_t)d * tstride, cin, tid);
+                if (act) {
+                    aring[d] = alpha[(size_t)d * sstride + tid];
+                    bring[d] = beta[(size_t)(d + 1) * sstride + tid];
+                    mring[d] = bmax[(size_t)(d + 1) * sstride + tid];
+                }
+            }
+        }
+        const int j = tid;
+        const int jq = j / NB;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int t0 = 0; t0 < T; t0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int t = t0 + d;
+                if (t < T) {
+                    float *m = sM + (t & 1) * cpad;
+                    ring[d].store(m, cin, tid);
+                    if (act) sG[(t & 1) * S + j] = aring[d];
+                    const float b1j = bring[d], m1j = mring[d];
+                    if (t + DEPTH < T) {
+                        ring[d].load(sc + (size_t)(t + DEPTH) * tstride, cin, tid);
+                        if (act) {
+                            aring[d] = alpha[(size_t)(t + DEPTH) * sstride + tid];
+                            bring[d] = beta[(size_t)(t + DEPTH + 1) * sstride + tid];
+                            mring[d] = bmax[(size_t)(t + DEPTH + 1) * sstride + tid];
+                        }
+                    }
+                    __syncthreads();
+                    // finalise the previous step's arg-max (partials were written before this barrier)
+                    if (tid == 0 && t > 0) {
+                        const float *rv = sRv + ((t - 1) & 1) * (BS / 64);
+                        const int *ri = sRi + ((t - 1) & 1) * (BS / 64);
+                        float bv = rv[0];
+                        int bi = ri[0];
+                        for (int w = 1; w < BS / 64; ++w)
+                            if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+                        sLab[t - 1] = (int8_t)(bi % E);
+                    }
+                    float best = -__builtin_inff();
+                    int bestc = 0x7fffffff;
+                    if (act) {
+                        const float *a0 = sG + (t & 1) * S;
+                        const float *am = sX + (t & 1) * S;
+                        float mm;
+                        {
+                            const float xx = ((a0[j] + score_at<NB, HB>(m, j, 0, blank)) + b1j) - logZ;
+                            const float Q = xb_logf(xb_expf(xx) + 1e-8f);
+                            const float av = am[j];
+                            mm = Q + av;
+                            best = (av + Q) + m1j;
+                            bestc = j * E;
+                        }
+#pragma unroll
+                        for (int k = 1; k < E; ++k) {
+                            const int src = (k - 1) * hi + jq;
+                            const float xx = ((a0[src] + score_at<NB, HB>(m, j, k, blank)) + b1j) - logZ;
+                            const float Q = xb_logf(xb_expf(xx) + 1e-8f);
+                            const float av = am[src];
+                            mm = maxf(mm, Q + av);
+                            const float scv = (av + Q) + m1j;
+                            if (scv > best) { best = scv; bestc = j * E + k; }
+                        }
+                        sX[((t + 1) & 1) * S + j] = mm;
+                    }
+                    // wave arg-max, ties to the lowest flat index
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const float ov = __shfl_xor(best, off, 64);
+                        const int oi = __shfl_xor(bestc, off, 64);
+                        if (ov > best || (ov == best && oi < bestc)) { best = ov; bestc = oi; }
+                    }
+                    if (lane == 0) {
+                        sRv[(t & 1) * (BS / 64) + wave] = best;
+                        sRi[(t & 1) * (BS / 64) + wave] = bestc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float *rv = sRv + ((T - 1) & 1) * (BS / 64);
+            const int *ri = sRi + ((T - 1) & 1) * (BS / 64);
+            float bv = rv[0];
+            int bi = ri[0];
+            for (int w = 1; w < BS / 64; ++w)
+                if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+            sLab[T - 1] = (int8_t)(bi % E);
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------ labels out + path_to_str + left-pack
+    if (p.labels)
+        for (int t = tid; t < T; t += BS) p.labels[(size_t)n * T + t] = sLab[t];
+    if (p.seq || p.seq_len) {
+        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints, sM is free now (cpad*2 >= BS+1 checked on host)
+        const int per = (T + BS - 1) / BS;
+        const int lo = tid * per, hiT = (lo + per < T) ? lo + per : T;
+        int cnt = 0;
+        for (int t = lo; t < hiT; ++t) cnt += sLab[t] != 0;
+        sCnt[tid + 1] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            sCnt[0] = 0;
+            for (int w = 1; w <= BS; ++w) sCnt[w] += sCnt[w - 1];
+        }
+        __syncthreads();
+        const int total = sCnt[BS];
+        if (p.seq) {
+            int8_t *out = p.seq + (size_t)n * T;
+            int pos = sCnt[tid];
+            for (int t = lo; t < hiT; ++t) {
+                const int l = sLab[t];
+                if (l != 0) out[pos++] = (int8_t)p.alphabet[l];
+            }
+            for (int t = total + tid; t < T; t += BS) out[t] = 0;
+        }
+        if (p.seq_len && tid == 0) p.seq_len[n] = total;
+    }
+}
+
+template <int NB, int BS>
+hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
+{
+    const int cpad = (p.cin + 3) & ~3;
+    size_t lds = sizeof(float) * (2 * (size_t)cpad + 6 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
+                 sizeof(float) * 4 + (size_t)p.T;
+    lds = (lds + 15) & ~(size_t)15;
+    dim3 grid(p.N), block(BS);
+#define XB_LAUNCH(VW, HB) hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB>), grid, block, lds, stream, p)
+    if (p.has_blank) {
+        if (vw == 4) XB_LAUNCH(4, true); else if (vw == 2) XB_LAUNCH(2, true); else XB_LAUNCH(1, true);
+    } else {
+        if (vw == 4) XB_LAUNCH(4, false); else if (vw == 2) XB_LAUNCH(2, false); else XB_LAUNCH(1, false);
+    }
+#undef XB_LAUNCH
+    return hipGetLastError();
+}
+
+template <int NB>
+hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
+{
+    if (p.S <= 64) return launch_nb_bs<NB, 64>(p, vw, stream);
+    if (p.S <= 128) return launch_nb_bs<NB, 128>(p, vw, stream);
+    if (p.S <= 256) return launch_nb_bs<NB, 256>(p, vw, stream);
+    return launch_nb_bs<NB, 1024>(p, vw, stream);
+}
+
+}  // namespace
+
+namespace xb {
+
+// Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:
+//   S = NB^state_len <= 1024, cin = S*(NB+1) or S*NB, ld >= cin, 2*cpad >= BS+1 (pack scratch).
+hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
+{
+    if (p.S < 1 || p.S > 1024 || p.T < 1 || p.N < 1) return hipErrorInvalidValue;
+    const int E = p.nb + 1;
+    if (p.cin != (p.has_blank ? p.S * E : p.S * p.nb) || p.ld < p.cin) return hipErrorInvalidValue;
+    const int bs = p.S <= 64 ? 64 : p.S <= 128 ? 128 : p.S <= 256 ? 256 : 1024;
+    if (2 * ((p.cin + 3) & ~3) < bs + 1) return hipErrorInvalidValue;
+    int vw = 1;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p.scores);
+    // vector loads may run into the row's padding columns (ld >= cin rounded up), never past the row
+    if (p.ld % 4 == 0 && p.ld >= ((p.cin + 3) & ~3) && a % 16 == 0) vw = 4;
+    else if (p.ld % 2 == 0 && p.ld >= ((p.cin + 1) & ~1) && a % 8 == 0) vw = 2;
+    switch (p.nb) {
+    case 4: return launch_nb<4>(p, vw, stream);
+    case 5: return launch_nb<5>(p, vw, stream);
+    case 6: return launch_nb<6>(p, vw, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace xb

@@ -1,0 +1,562 @@
+// xb_encoder.hip -- Conv1d front-end, split-fp16 MFMA GEMM and LSTM recurrence for gfx950.
+//
+// Replaces Model.forward = bonito.nn Serial of (ub-bonito/bonito/crf/model.py:147-160):
+//   Convolution x3 (nn.py:57-68), Permute (nn.py:156-164), LSTM x5 with alternating direction
+//   (nn.py:176-193,216-220), LinearCRFEncoder (nn.py:112-133).
+//
+// Arithmetic: the dense contractions (conv3 as an im2col GEMM, the LSTM input and recurrent
+// projections, the CRF linear layer) run on v_mfma_f32_32x32x16_f16 with every fp32 operand
+// split into hi + lo fp16 halves and three products (hi*hi + hi*lo + lo*hi) accumulated in
+// fp32 -- ~2^-21 relative operand error, i.e. fp32-grade scores (|err| ~1e-5) at 3/16 of the
+// cost of the exact-f32 MFMA.  nsplit = 1 keeps only hi*hi (the reference's model.half()).
+// Gates, cell state and activations are fp32 VALU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xb_internal.h"
+
+namespace {
+
+using xb::half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    // 1 - 2/(e^{2x}+1); exact limits at +-inf, abs error ~1e-7
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+__device__ __forceinline__ float silu(float x) { return x * fast_sigmoid(x); }
+
+__device__ __forceinline__ void split_f16(float v, half_t &hi, half_t &lo)
+{
+    hi = (half_t)v;
+    lo = (half_t)(v - (float)hi);
+}
+
+// ======================================================================================
+// conv1 + conv2 + im2col of conv3's input
+// ======================================================================================
+constexpr int CF_TT = 32;   // output time steps per workgroup
+
+__global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * CF_TT;
+    const int W = p.winlen, ST = p.stride, pad = W / 2, L = p.L;
+    const int nq = (CF_TT - 1) * ST + W;      // conv2 positions needed
+    const int q0 = t0 * ST - pad;
+    float *sig = reinterpret_cast<float *>(smem_raw);   // [nq + 8]
+    float *a1 = sig + nq + 8;                            // [4][nq + 4]
+    float *a2 = a1 + 4 * (nq + 4);                       // [16][nq]
+    float *w2s = a2 + 16 * nq;                           // [320] + b2 [16] + w1 [20] + b1 [4]
+    float *b2s = w2s + 320, *w1s = b2s + 16, *b1s = w1s + 20;
+
+    for (int i = tid; i < 320; i += 256) w2s[i] = p.w2[i];
+    if (tid < 16) b2s[tid] = p.b2[tid];
+    if (tid < 20) w1s[tid] = p.w1[tid];
+    if (tid < 4) b1s[tid] = p.b1[tid];
+    const float *x = p.signal + (size_t)n * L;
+    for (int i = tid; i < nq + 8; i += 256) {
+        const int pos = q0 - 4 + i;
+        sig[i] = (pos >= 0 && pos < L) ? x[pos] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * (nq + 4); i += 256) {
+        const int c = i / (nq + 4), r = i % (nq + 4);
+        const int pos = q0 - 2 + r;
+        float v = 0.0f;
+        if (pos >= 0 && pos < L) {
+            float acc = b1s[c];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc += w1s[c * 5 + k] * sig[r + k];
+            v = silu(acc);
+        }
+        a1[c * (nq + 4) + r] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * nq; i += 256) {
+        const int c = i / nq, r = i % nq;
+        const int pos = q0 + r;
+        float v = 0.0f;
+        if (pos >= 0 && pos < L) {
+            float acc = b2s[c];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc += w2s[(c * 4 + ci) * 5 + k] * a1[ci * (nq + 4) + r + k];
+            v = silu(acc);
+        }
+        a2[c * nq + r] = v;
+    }
+    __syncthreads();
+    const int kp = p.kp, kv = 16 * W;
+    for (int i = tid; i < CF_TT * kp; i += 256) {
+        const int tt = i / kp, col = i % kp;
+        const int t = t0 + tt;
+        if (t >= p.T) break;
+        float v = 0.0f;
+        if (col < kv) {
+            const int c = col / W, k = col % W;
+            v = a2[c * nq + tt * ST + k];
+        }
+        half_t hi, lo;
+        split_f16(v, hi, lo);
+        const size_t o = ((size_t)t * p.N + n) * kp + col;
+        p.a_hi[o] = hi;
+        p.a_lo[o] = lo;
+    }
+}
+
+// ======================================================================================
+// split-fp16 MFMA GEMM:  D[m][n] = sum_k A[m][k] B[n][k]
+// 128x128 tile, BK = 32, 4 waves (2x2), each 64x64 = 2x2 MFMA 32x32x16 tiles.
+// LDS image per operand part: [128 rows][4 cells of 16 B], cell index XOR-swizzled with
+// (row >> 2) & 3 so that every 16-lane ds_read_b128 group hits 16 distinct bank slots.
+// ======================================================================================
+constexpr int GT = 128, GBK = 32;
+
+struct Stage2 { uint4 v[2]; };
+
+// 128 rows x 32 halves of one operand part = 512 cells of 16 B; thread `tid` moves cells tid, tid+256
+__device__ __forceinline__ Stage2 load_part(int tid, int kt, const half_t *base, int ldp, int row0, int rlast)
+{
+    Stage2 s;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        int rg = row0 + row;
+        rg = rg > rlast ? rlast : rg;
+        s.v[i] = *reinterpret_cast<const uint4 *>(base + (size_t)rg * ldp + kt * GBK + kc * 8);
+    }
+    return s;
+}
+__device__ __forceinline__ void write_part(int tid, uint4 *part, const Stage2 &s)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        part[row * 4 + (kc ^ ((row >> 2) & 3))] = s.v[i];
+    }
+}
+
+template <int EPI, int NSPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(xb::GemmParams p)
+{
+    constexpr int NPART = NSPLIT == 3 ? 4 : 2;               // Ahi,(Alo),Bhi,(Blo)
+    __shared__ uint4 lds[2][NPART][GT * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int nk = p.K / GBK;
+
+    // staging registers: one 16-byte cell pair per operand part (A hi, A lo, B hi, B lo)
+    Stage2 sAh, sAl, sBh, sBl;
+    const int Mlast = p.M - 1, Nlast = p.Nn - 1;
+#define XB_LOAD_REGS(kt)                                                              \
+    do {                                                                              \
+        sAh = load_part(tid, (kt), p.a_hi, p.lda, m0, Mlast);                         \
+        sBh = load_part(tid, (kt), p.b_hi, p.ldb, n0, Nlast);                         \
+        if (NSPLIT == 3) {                                                            \
+            sAl = load_part(tid, (kt), p.a_lo, p.lda, m0, Mlast);                     \
+            sBl = load_part(tid, (kt), p.b_lo, p.ldb, n0, Nlast);                     \
+        }                                                                             \
+    } while (0)
+#define XB_WRITE_LDS(st)                                                              \
+    do {                                                                              \
+        write_part(tid, lds[(st)][0], sAh);                                           \
+        write_part(tid, lds[(st)][NSPLIT == 3 ? 2 : 1], sBh);                         \
+        if (NSPLIT == 3) {                                                            \
+            write_part(tid, lds[(st)][1], sAl);                                       \
+            write_part(tid, lds[(st)][3], sBl);                                       \
+        }                                                                             \
+    } while (0)
+    auto frag = [&](int st, int q, int rb, int s) -> half8 {
+        const int row = rb * 32 + (lane & 31), kc = 2 * s + (lane >> 5);
+        const uint4 v = lds[st][q][row * 4 + (kc ^ ((row >> 2) & 3))];
+        return __builtin_bit_cast(half8, v);
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    XB_LOAD_REGS(0);
+    XB_WRITE_LDS(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) XB_LOAD_REGS(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = frag(st, 0, 2 * wm + i, s);
+                bh[i] = frag(st, NSPLIT == 3 ? 2 : 1, 2 * wn + i, s);
+                if (NSPLIT == 3) {
+                    al[i] = frag(st, 1, 2 * wm + i, s);
+                    bl[i] = frag(st, 3, 2 * wn + i, s);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (NSPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) XB_WRITE_LDS(st ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column n (lane & 31) and 16 rows per tile
+#undef XB_LOAD_REGS
+#undef XB_WRITE_LDS
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Nn) continue;
+            const float bias = p.bias ? p.bias[n] : 0.0f;
+            int ocol = n;
+            if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const float v = acc[i][j][r] + bias;
+                if (EPI == xb::EPI_BIAS_F32) {
+                    p.out_f32[(size_t)m * p.ldc + n] = v;
+                } else if (EPI == xb::EPI_SILU_SPLIT) {
+                    half_t hi, lo;
+                    split_f16(silu(v), hi, lo);
+                    p.out_hi[(size_t)m * p.ldc + n] = hi;
+                    p.out_lo[(size_t)m * p.ldc + n] = lo;
+                } else {
+                    p.out_f32[(size_t)m * p.ldc + ocol] = p.scale * fast_tanh(v);
+                    if (p.expand && n % p.nb == 0) p.out_f32[(size_t)m * p.ldc + ocol - 1] = p.blank;
+                }
+            }
+        }
+}
+
+// ======================================================================================
+// LSTM recurrence.
+// A *group* = LG_BN chunks; its F/32 member workgroups each own 32 hidden units (128
+// gate-interleaved rows of W_hh: wave w holds rows [32w, 32w+32) = units 8w..8w+7 as MFMA
+// A-operand fragments in registers for the whole launch).  Per step a member needs the whole
+// h_{t-1} of its group's chunks: it is pulled from the layer output buffer (the members'
+// previous-step stores) into LDS by LDS-DMA in K pieces of KP columns, double buffered against
+// the MFMAs.  MFMA tile orientation: rows = gate rows (so one lane owns i,f,g,o of a unit in
+// four consecutive accumulator registers), columns = chunks.
+// persistent = 1: all steps in one launch; members of a group meet after every step on a
+// monotonic arrival counter (plain stores -> every wave vmcnt(0) -> barrier -> one lane:
+// agent release fence, vmcnt(0), relaxed agent atomic add; consumer: one lane polls relaxed,
+// agent acquire fence, vmcnt(0), barrier, then loads).  Every spin is bounded.
+// ======================================================================================
+constexpr int LG_BN = 64;        // chunks per group (2 MFMA column tiles)
+constexpr int LG_UNITS = 32;     // hidden units per member workgroup
+constexpr unsigned long long LG_SPIN_CYCLES = 4000000000ull;   // ~2 s at 2 GHz
+
+__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int KS, int NSPLIT>
+__global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
+{
+    constexpr int F = KS * 16;
+    constexpr int KP = F < 128 ? F : 128;       // columns per piece
+    constexpr int NP = F / KP;                  // pieces per step
+    constexpr int KSP = KP / 16;                // MFMA k-steps per piece
+    constexpr int CPR = KP / 8;                 // 16-byte cells per row per piece
+    constexpr int SWZ = (CPR & -CPR) - 1;       // XOR mask that stays inside the row
+    constexpr int NPARTS = NSPLIT == 3 ? 2 : 1; // hi (, lo)
+    constexpr int PIECE_BYTES = LG_BN * KP * 2; // one part of one piece
+    static_assert(F % KP == 0, "feature size must be a multiple of the piece width");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
+    half_t *sT = reinterpret_cast<half_t *>(smem_raw + 2 * NPARTS * PIECE_BYTES); // [NPARTS][64][32]
+    int *sFlag = reinterpret_cast<int *>(sT + NPARTS * LG_BN * LG_UNITS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int members = F / LG_UNITS;
+    const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
+    const int g8 = (ngroups + 7) & ~7;
+    const int grp = blockIdx.x % g8, mb = blockIdx.x / g8;
+    if (grp >= ngroups) return;
+    const int N = p.N, T = p.T;
+    const int nlast = p.n0 + p.nslab - 1;
+    const int cbase = p.n0 + grp * LG_BN;        // first chunk of the group
+    const int hsel = lane >> 5;
+    const int ubase = mb * LG_UNITS + wid * 8;   // first unit of this wave
+
+    // ---- W_hh fragments: row = gate-interleaved (unit*4+gate), lane l: row (l&31), k-chunk (l>>5)
+    half8 wh[KS], wl[KS];
+    {
+        const size_t row = (size_t)ubase * 4 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            wh[k] = *reinterpret_cast<const half8 *>(p.w_hi + row * F + k * 16 + hsel * 8);
+            if (NSPLIT == 3) wl[k] = *reinterpret_cast<const half8 *>(p.w_lo + row * F + k * 16 + hsel * 8);
+        }
+    }
+
+    // ---- cell state: lane owns (chunk = 32*nt + (l&31), unit = ubase + 2*rg + hsel)
+    float c[2][4];
+    int chunk[2];
+    bool cvalid[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = cbase + nt * 32 + (lane & 31);
+        cvalid[nt] = n <= nlast;
+        chunk[nt] = cvalid[nt] ? n : nlast;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) c[nt][rg] = p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel];
+    }
+
+    unsigned *cnt = p.sync + (size_t)grp * 32;
+
+    for (int s = p.s_begin; s < p.s_end; ++s) {
+        const int t = p.reverse ? T - 1 - s : s;
+        const int tprev = p.reverse ? t + 1 : t - 1;
+
+        // accumulators start from the input projection (+ biases)
+        floatx16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float *g = p.gin + ((size_t)t * N + chunk[nt]) * (4 * F) + (size_t)ubase * 4;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (2 * rg + hsel) * 4);
+                acc[nt][4 * rg + 0] = v.x; acc[nt][4 * rg + 1] = v.y;
+                acc[nt][4 * rg + 2] = v.z; acc[nt][4 * rg + 3] = v.w;
+            }
+        }
+
+        if (s > 0) {
+            if (p.persistent && s > p.s_begin) {
+                // wait until every member of the group has published h_{t-1}
+                if (tid == 0) {
+                    const unsigned target = (unsigned)members * (unsigned)(s - p.s_begin);
+                    const unsigned long long t0 = __builtin_readcyclecounter();
+                    int ok = 1;
+                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                            __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES) {
+                            __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 0;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    *sFlag = ok;
+                }
+                __syncthreads();
+                if (*sFlag == 0) return;
+            }
+
+            // h_{t-1} of the group's chunks, piece by piece through LDS
+            auto issue_piece = [&](int pc) {
+                unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
+                // CPR wave-instructions per part; wave w issues q = w, w+4, ...
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) {
+                    const half_t *y = part == 0 ? p.y_hi : p.y_lo;
+                    for (int q = wid; q < CPR; q += 4) {
+                        const int cell = 64 * q + lane;
+                        const int row = cell / CPR, pos = cell % CPR;
+                        const int kc = pos ^ (row & SWZ);
+                        int n = cbase + row;
+                        n = n > nlast ? nlast : n;
+                        const half_t *src = y + ((size_t)tprev * N + n) * F + pc * KP + kc * 8;
+                        dma16(src, buf + part * PIECE_BYTES + q * 1024);
+                    }
+                }
+            };
+            issue_piece(0);
+            __syncthreads();
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                if (pc + 1 < NP) issue_piece(pc + 1);
+                const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < KSP; ++ks) {
+                    const int kg = pc * KSP + ks;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int row = nt * 32 + (lane & 31);
+                        const int pos = (2 * ks + hsel) ^ (row & SWZ);
+                        const half8 bh = *reinterpret_cast<const half8 *>(buf + (row * CPR + pos) * 16);
+                        if (NSPLIT == 3) {
+                            const half8 bl = *reinterpret_cast<const half8 *>(buf + PIECE_BYTES + (row * CPR + pos) * 16);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kg], bh, acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], bl, acc[nt], 0, 0, 0);
+                        }
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], bh, acc[nt], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // gates -> cell -> hidden; stage h (split fp16) in LDS as [chunk][unit]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
+                const float fg = fast_sigmoid(acc[nt][4 * rg + 1]);
+                const float gg = fast_tanh(acc[nt][4 * rg + 2]);
+                const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
+                const float cn = fg * c[nt][rg] + ig * gg;
+                c[nt][rg] = cn;
+                const float hv = og * fast_tanh(cn);
+                half_t hi, lo;
+                split_f16(hv, hi, lo);
+                const int o = (nt * 32 + (lane & 31)) * LG_UNITS + wid * 8 + 2 * rg + hsel;
+                sT[o] = hi;
+                if (NSPLIT == 3) sT[LG_BN * LG_UNITS + o] = lo;
+            }
+        __syncthreads();
+        // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part
+        {
+            const int row = tid >> 2, cc = tid & 3;
+            const int n = cbase + row;
+            if (n <= nlast) {
+                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + cc * 8;
+                *reinterpret_cast<uint4 *>(p.y_hi + o) = *reinterpret_cast<const uint4 *>(sT + row * LG_UNITS + cc * 8);
+                if (NSPLIT == 3)
+                    *reinterpret_cast<uint4 *>(p.y_lo + o) =
+                        *reinterpret_cast<const uint4 *>(sT + LG_BN * LG_UNITS + row * LG_UNITS + cc * 8);
+                else
+                    *reinterpret_cast<uint4 *>(p.y_lo + o) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (p.persistent && s + 1 < p.s_end) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            __syncthreads();   // sT is rewritten next step
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        if (cvalid[nt])
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel] = c[nt][rg];
+}
+
+template <int KS>
+hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
+{
+    constexpr int F = KS * 16;
+    constexpr int KP = F < 128 ? F : 128;
+    const int nparts = p.nsplit == 3 ? 2 : 1;
+    const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
+    const int g8 = (ngroups + 7) & ~7;
+    const int members = F / LG_UNITS;
+    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * LG_BN * LG_UNITS * 2 + 16;
+    dim3 grid(g8 * members), block(256);
+    if (p.nsplit == 3)
+        hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((lstm_kernel<KS, 1>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
+{
+    dim3 grid((p.Nn + GT - 1) / GT, (p.M + GT - 1) / GT), block(256);
+    if (p.nsplit == 3)
+        hipLaunchKernelGGL((gemm_kernel<EPI, 3>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<EPI, 1>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+namespace xb {
+
+hipError_t launch_conv_front(const ConvFrontParams &p, hipStream_t stream)
+{
+    if (p.N < 1 || p.T < 1 || p.kp < 16 * p.winlen || p.kp % 32 != 0) return hipErrorInvalidValue;
+    const int nq = (CF_TT - 1) * p.stride + p.winlen;
+    const size_t lds = sizeof(float) * ((size_t)(nq + 8) + 4 * (nq + 4) + 16 * (size_t)nq + 360);
+    if (lds > 60000) return hipErrorInvalidValue;
+    dim3 grid((p.T + CF_TT - 1) / CF_TT, p.N), block(256);
+    hipLaunchKernelGGL(conv_front_kernel, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream)
+{
+    if (p.M < 1 || p.Nn < 1 || p.K < GBK || p.K % GBK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 ||
+        p.lda < p.K || p.ldb < p.K)
+        return hipErrorInvalidValue;
+    if (p.nsplit != 1 && p.nsplit != 3) return hipErrorInvalidValue;
+    switch (epilogue) {
+    case EPI_BIAS_F32: return launch_gemm_epi<EPI_BIAS_F32>(p, stream);
+    case EPI_SILU_SPLIT: return launch_gemm_epi<EPI_SILU_SPLIT>(p, stream);
+    case EPI_TANH_SCALE: return launch_gemm_epi<EPI_TANH_SCALE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool lstm_supported_features(int F)
+{
+    switch (F) {
+    case 32: case 64: case 96: case 128: case 256: case 384: case 512: case 768: return true;
+    default: return false;
+    }
+}
+int lstm_members(int F) { return F / LG_UNITS; }
+int lstm_group_chunks() { return LG_BN; }
+
+hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
+{
+    if (!lstm_supported_features(p.F) || p.nslab < 1 || p.s_begin < 0 || p.s_end > p.T || p.s_begin >= p.s_end)
+        return hipErrorInvalidValue;
+    if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
+    if (p.nsplit != 1 && p.nsplit != 3) return hipErrorInvalidValue;
+    switch (p.F / 16) {
+    case 2: return launch_lstm_ks<2>(p, stream);
+    case 4: return launch_lstm_ks<4>(p, stream);
+    case 6: return launch_lstm_ks<6>(p, stream);
+    case 8: return launch_lstm_ks<8>(p, stream);
+    case 16: return launch_lstm_ks<16>(p, stream);
+    case 24: return launch_lstm_ks<24>(p, stream);
+    case 32: return launch_lstm_ks<32>(p, stream);
+    case 48: return launch_lstm_ks<48>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace xb

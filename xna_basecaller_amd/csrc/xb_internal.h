@@ -1,0 +1,79 @@
+// xb_internal.h -- declarations shared by the translation units of libxnacall.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xb {
+
+typedef _Float16 half_t;
+
+// ---------------------------------------------------------------- CRF decode (xb_decode.hip)
+struct DecodeParams {
+    const float *scores;   // (T, N, ld) fp32, first `cin` columns of each row are used
+    int T, N, S, hi, nb;   // hi = nb^(state_len-1)
+    int cin, ld, has_blank;
+    float blank;
+    float *alpha, *beta, *bmax;   // (T+1, N, S) fp32 stashes
+    float *logz;                  // (N) or nullptr
+    int8_t *labels;               // (N, T) or nullptr
+    int8_t *seq;                  // (N, T) or nullptr
+    int32_t *seq_len;             // (N) or nullptr
+    char alphabet[8];
+};
+hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream);
+
+// ---------------------------------------------------------------- encoder (xb_encoder.hip)
+
+// conv1(1->4,k5,p2)+SiLU, conv2(4->16,k5,p2)+SiLU, then the im2col rows of conv3
+// (row (t*N+n), col c*winlen+k = a2[c][t*stride - winlen/2 + k]) as split fp16, K padded to kp.
+struct ConvFrontParams {
+    const float *signal;   // (N, L)
+    int N, L, T, winlen, stride, kp;
+    const float *w1, *b1;  // (4,1,5), (4)
+    const float *w2, *b2;  // (16,4,5), (16)
+    half_t *a_hi, *a_lo;   // (T*N, kp)
+};
+hipError_t launch_conv_front(const ConvFrontParams &p, hipStream_t stream);
+
+enum GemmEpilogue { EPI_BIAS_F32 = 0, EPI_SILU_SPLIT = 1, EPI_TANH_SCALE = 2 };
+
+// D[m][n] = sum_k A[m][k] * B[n][k]  (+ epilogue); A, B split fp16 (hi, lo), K multiple of 32.
+struct GemmParams {
+    const half_t *a_hi, *a_lo;   // (M, lda)
+    const half_t *b_hi, *b_lo;   // (Nn, ldb)
+    int M, Nn, K, lda, ldb;
+    const float *bias;           // (Nn) or nullptr
+    float *out_f32;              // EPI_BIAS_F32 / EPI_TANH_SCALE : (M, ldc)
+    half_t *out_hi, *out_lo;     // EPI_SILU_SPLIT : (M, ldc)
+    int ldc;
+    float scale;                 // EPI_TANH_SCALE
+    int nb, expand;              // EPI_TANH_SCALE : insert blank column in front of every nb outputs
+    float blank;
+    int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only
+};
+hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream);
+
+// One LSTM layer's recurrence over a slab of chunks.  Gate pre-activations of the input
+// projection (+ both biases) are in `gin` with gate-interleaved columns (col = unit*4 + gate,
+// gates i,f,g,o); w_hh rows are in the same order.  y receives h_t as split fp16.
+struct LstmParams {
+    const float *gin;            // (T, N, 4F)
+    const half_t *w_hi, *w_lo;   // (4F, F) gate-interleaved rows
+    half_t *y_hi, *y_lo;         // (T, N, F)
+    float *c_state;              // (N, F) fp32 cell state (in/out across launches)
+    int T, N, F;
+    int n0, nslab;               // chunks [n0, n0+nslab) are processed by this launch
+    int reverse;                 // time runs T-1..0
+    int s_begin, s_end;          // recurrence steps [s_begin, s_end) of this launch (s = 0 is the first step)
+    int persistent;              // 1: all steps in one launch with inter-workgroup sync
+    unsigned *sync;              // per-group arrival counters (zeroed before a persistent launch), stride 32 words
+    unsigned *error;             // set non-zero when a sync wait timed out
+    int nsplit;
+};
+hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
+// members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
+int lstm_members(int F);
+int lstm_group_chunks();
+bool lstm_supported_features(int F);
+
+}  // namespace xb

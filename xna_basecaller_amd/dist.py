@@ -1,0 +1,110 @@
+"""
+Multi-GPU layer: one process per GPU, reads sharded round-robin, no data-path collective, and ONE
+gather of the called sequences to rank 0 (RCCL over xGMI via torch.distributed's "nccl" backend on
+ROCm; "gloo" on CPU for tests).  The reference has no distributed code at all;
+reads are independent units, chunks of one read stay on one rank so that
+stitching is local.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["init_from_env", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier"]
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+def shard(items, rank_=None, world=None):
+    """Round-robin partition of an iterable of units (reads): unit i goes to rank i % world; yields (i, item)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    for i, item in enumerate(items):
+        if i % w == r:
+            yield i, item
+
+
+def _comm_device():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_called(records, dst=0):
+    """
+    records: list of (global_index, read_id, sequence, qstring) called on this rank.
+    Returns on rank `dst` the records of all ranks ordered by global_index (None elsewhere).
+    Wire format: all_gather of int64 byte counts, then all_gather of uint8 payloads padded to the
+    maximum count (what NCCL/RCCL offers without variable-size collectives).
+    """
+    w = world_size()
+    if w == 1:
+        return sorted(records, key=lambda r: r[0])
+    lines = ["%d\t%s\t%s\t%s" % (i, rid, seq, q) for i, rid, seq, q in records]
+    payload = np.frombuffer("\n".join(lines).encode("ascii"), dtype=np.uint8)
+    dev = _comm_device()
+    count = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(w)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    width = max(max(counts), 1)
+    buf = torch.zeros(width, dtype=torch.uint8, device=dev)
+    if payload.size:
+        buf[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
+    out = torch.empty(w * width, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    if rank() != dst:
+        return None
+    out = out.cpu().numpy().reshape(w, width)
+    merged = []
+    for r in range(w):
+        if counts[r] == 0:
+            continue
+        for line in out[r, :counts[r]].tobytes().decode("ascii").split("\n"):
+            i, rid, seq, q = line.split("\t")
+            merged.append((int(i), rid, seq, q))
+    merged.sort(key=lambda r: r[0])
+    return merged
+
+
+def gather_packed(seq, lens):
+    """
+    Fixed-shape gather for the synthetic bench: seq (n, T) int8 left-packed + lens (n,) int32 device
+    tensors of every rank -> (world, n, T), (world, n) on every rank (all_gather; payload ~T bytes per chunk).
+    """
+    w = world_size()
+    if w == 1:
+        return seq[None], lens[None]
+    # all_gather_into_tensor concatenates along dim 0 (the layout both gloo and nccl accept)
+    out_s = torch.empty((w * seq.shape[0],) + tuple(seq.shape[1:]), dtype=seq.dtype, device=seq.device)
+    out_l = torch.empty((w * lens.shape[0],) + tuple(lens.shape[1:]), dtype=lens.dtype, device=lens.device)
+    dist.all_gather_into_tensor(out_s, seq.contiguous())
+    dist.all_gather_into_tensor(out_l, lens.contiguous())
+    return out_s.view((w,) + tuple(seq.shape)), out_l.view((w,) + tuple(lens.shape))
