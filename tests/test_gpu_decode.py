@@ -1,0 +1,125 @@
+"""GPU: the HIP CRF decode (through the C ABI) against the oracle -- bit-exact labels / packed sequences."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, random_scores
+from xna_basecaller_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(nb, T, N, sl=3, features=32):
+    return _lib.Context(0, nb, sl, features, 19, 5, 5.0, 2.0, T * 5, N)
+
+
+def _check(ctx, sc, nb, alphabet, sl=3, blank=None):
+    seq, lens, labels = ctx.decode(sc, alphabet, want_labels=True)
+    ref = oracle.decode(sc, nb, sl, blank_score=blank)["labels"]
+    assert np.array_equal(labels, ref), "label mismatches: %d of %d" % ((labels != ref).sum(), ref.size)
+    rseq, _, rlens = oracle.pack(ref, alphabet)
+    assert np.array_equal(lens, rlens)
+    assert np.array_equal(seq, rseq)
+
+
+@pytest.mark.parametrize("nb", [4, 5, 6])
+@pytest.mark.parametrize("with_blank", [True, False])
+def test_decode_bit_exact_random(nb, with_blank):
+    alphabet = "NACGTXY"[:nb + 1]
+    T, N = 203, 5                                   # T not a multiple of the prefetch depth
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=10 + nb, with_blank=with_blank)
+    _check(ctx, sc, nb, alphabet, blank=None if with_blank else 2.0)
+    ctx.close()
+
+
+def test_decode_golden_fixture_scores():
+    meta = json.load(open(os.path.join(GOLDEN, "decode_meta.json")))
+    z = np.load(os.path.join(GOLDEN, "decode_small.npz"))
+    for case in meta["cases"]:
+        sc = z[case["name"] + "/scores_f16"].astype(np.float32)
+        T, N, _ = sc.shape
+        ctx = _ctx(case["nb"], T, N)
+        _check(ctx, sc, case["nb"], "".join(case["labels"]))
+        ctx.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 8])
+def test_decode_tiny_T(T):
+    ctx = _ctx(6, 8, 3)
+    _check(ctx, random_scores(T, 3, 6, seed=T), 6, "NACGTXY")
+    ctx.close()
+
+
+def test_decode_ties_and_extremes():
+    nb, T, N = 6, 50, 4
+    S, E = nb ** 3, nb + 1
+    ctx = _ctx(nb, T, N)
+    sc = np.zeros((T, N, S * E), np.float32)                       # every path ties: lowest flat index wins
+    _check(ctx, sc, nb, "NACGTXY")
+    sc = random_scores(T, N, nb, seed=1)
+    sc[:, 1] = np.round(sc[:, 1])                                   # heavy ties on a coarse grid
+    sc[:, 2] *= 8.0                                                 # scores far outside tanh range: deep underflow
+    sc[:, 3] = -5.0
+    sc[:, 3].reshape(T, S, E)[:, :, 0] = 5.0                        # blank dominates: empty call
+    _check(ctx, sc, nb, "NACGTXY")
+    seq, lens = ctx.decode(sc, "NACGTXY")
+    assert lens[3] == 0 and not seq[3].any()
+    ctx.close()
+
+
+def test_decode_full_length_chunks():
+    """BASELINE size T=2000 (chunksize 10000), 6-base CRF: oracle on all chunks of a small batch."""
+    nb, T, N = 6, 2000, 6
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=99)
+    _check(ctx, sc, nb, "NACGTXY")
+    ctx.close()
+
+
+def test_decode_properties_large_batch():
+    """Size-independent properties at a larger batch: per-chunk independence and batch-slicing invariance."""
+    nb, T, N = 5, 400, 96
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=5)
+    seq, lens, labels = ctx.decode(sc, "NACGTX", want_labels=True)
+    sub = np.ascontiguousarray(sc[:, 17:49])
+    seq2, lens2, labels2 = ctx.decode(sub, "NACGTX", want_labels=True)
+    assert np.array_equal(labels[17:49], labels2) and np.array_equal(lens[17:49], lens2)
+    assert np.array_equal((labels != 0).sum(1), lens)
+    ref = oracle.decode(np.ascontiguousarray(sc[:, :8]), nb, 3)["labels"]
+    assert np.array_equal(labels[:8], ref)
+    ctx.close()
+
+
+def test_decode_dev_pointers():
+    import torch
+    nb, T, N = 6, 64, 4
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=2)
+    d_sc = torch.from_numpy(sc).cuda()
+    d_lab = torch.empty((N, T), dtype=torch.int8, device="cuda")
+    d_seq = torch.empty((N, T), dtype=torch.int8, device="cuda")
+    d_len = torch.empty((N,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.decode_dev(d_sc.data_ptr(), T, N, True, "NACGTXY", d_lab.data_ptr(), d_seq.data_ptr(), d_len.data_ptr())
+    ctx.synchronize()
+    ref = oracle.decode(sc, nb, 3)["labels"]
+    assert np.array_equal(d_lab.cpu().numpy(), ref)
+    ctx.close()
+
+
+def test_abi_error_paths():
+    ctx = _ctx(6, 16, 2)
+    with pytest.raises(_lib.XbError) as e:
+        ctx.decode(random_scores(16, 3, 6), "NACGTXY")              # batch above max_batch
+    assert e.value.code == -1 and "max_batch" in str(e.value)
+    with pytest.raises(_lib.XbError) as e:
+        ctx.encode(np.zeros((1, 80), np.float32))                   # weights never loaded
+    assert e.value.code == -4
+    with pytest.raises(_lib.XbError):
+        ctx.decode(random_scores(17, 2, 6), "NACGTXY")              # T above the context's T
+    ctx.close()

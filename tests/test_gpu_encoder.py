@@ -1,0 +1,101 @@
+"""GPU: the HIP encoder (conv front-end, split-fp16 MFMA GEMMs, LSTM) through the C ABI against the golden
+fixtures made by the reference's nn.py modules and against the oracle.  Tolerance: |score error| <= 1e-3
+(north star); the default split-fp16 (3 product) arithmetic lands around 1e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, encoder_shapes, seeded_state_dict
+from xna_basecaller_amd import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _golden_case(name):
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))
+    case = [c for c in meta["cases"] if c["name"] == name][0]
+    z = np.load(os.path.join(GOLDEN, "encoder_small.npz"))
+    sd = {k: z["%s/w/%s" % (name, k)] for k in case["keys"]}
+    return case, sd, z[name + "/signal"], z[name + "/scores"]
+
+
+@pytest.mark.parametrize("name", ["f32_nb6", "f32_nb4_long", "f48_nb5", "f16_nb4"])
+@pytest.mark.parametrize("lstm_mode", [1, 2])
+def test_encoder_small_golden(name, lstm_mode):
+    case, sd, signal, ref = _golden_case(name)
+    F, nb = case["features"], len(case["labels"]) - 1
+    if F % 32:
+        with pytest.raises(_lib.XbError) as e:
+            _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, case["L"], case["N"])
+        assert "features" in str(e.value)
+        return
+    ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, case["L"], case["N"], lstm_mode=lstm_mode)
+    ctx.load_state_dict(sd)
+    got = ctx.encode(signal[:, 0, :], expand_blanks=True)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err < TOL, err
+    assert err < 1e-4, "split-fp16 arithmetic should be ~1e-5, got %g" % err
+    S = nb ** 3
+    assert np.all(got.reshape(got.shape[0], got.shape[1], S, nb + 1)[..., 0] == 2.0)
+    nob = ctx.encode(signal[:, 0, :], expand_blanks=False)
+    assert np.array_equal(nob.reshape(nob.shape[0], nob.shape[1], S, nb),
+                          got.reshape(got.shape[0], got.shape[1], S, nb + 1)[..., 1:])
+    ctx.close()
+
+
+@pytest.mark.parametrize("features,nb,L,N", [(64, 5, 600, 3), (96, 4, 800, 70), (128, 6, 400, 2)])
+def test_encoder_vs_oracle(features, nb, L, N):
+    keys, shapes = encoder_shapes(features, nb)
+    sd = seeded_state_dict(keys, shapes, seed=features + nb)
+    x = np.random.default_rng(L).standard_normal((N, L)).astype(np.float32)
+    ref = oracle.encode(x, sd, features, nb, 3)
+    for mode in (1, 2):
+        ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        got = ctx.encode(x)
+        assert np.abs(got - ref).max() < 1e-4
+        ctx.close()
+
+
+def test_encoder_per_step_and_persistent_agree_bitwise():
+    keys, shapes = encoder_shapes(96, 6)
+    sd = seeded_state_dict(keys, shapes, seed=5)
+    x = np.random.default_rng(3).standard_normal((130, 1000)).astype(np.float32)   # 3 groups, last one ragged
+    outs = []
+    for mode in (1, 2):
+        ctx = _lib.Context(0, 6, 3, 96, 19, 5, 5.0, 2.0, 1000, 130, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        outs.append(ctx.encode(x))
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_encoder_full_size_golden():
+    """features 768 (24.85 M parameters), weights regenerated from the fixture's seed."""
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))["full"]
+    z = np.load(os.path.join(GOLDEN, "encoder_full.npz"))
+    sd = seeded_state_dict(meta["keys"], meta["shapes"], meta["seed"])
+    x = np.random.default_rng(meta["signal_seed"]).standard_normal((meta["N"], meta["L"])).astype(np.float32)
+    for mode in (1, 2):
+        ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, meta["L"], meta["N"], lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        got = ctx.encode(x)
+        err = max(np.abs(got[0] - z["scores_t0"]).max(), np.abs(got[-1] - z["scores_tlast"]).max(),
+                  np.abs(got[50, :, ::7] - z["scores_mid"]).max())
+        assert err < 1e-4, err
+        ctx.close()
+
+
+def test_encoder_fp16_fast_mode_is_close():
+    """precision = f16 (single product, the reference's model.half()): looser than the default, reported only."""
+    case, sd, signal, ref = _golden_case("f32_nb6")
+    ctx = _lib.Context(0, 6, 3, 32, 19, 5, 5.0, 2.0, case["L"], case["N"], precision=_lib.XB_PREC_F16)
+    ctx.load_state_dict(sd)
+    got = ctx.encode(signal[:, 0, :])
+    assert np.abs(got - ref).max() < 2e-2
+    ctx.close()

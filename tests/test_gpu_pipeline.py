@@ -1,0 +1,76 @@
+"""GPU: the reference-shaped pipeline (Model / compute_scores / basecall) end to end against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import encoder_shapes, make_config, seeded_state_dict
+from xna_basecaller_amd import util
+from xna_basecaller_amd.crf import Model, basecall
+from xna_basecaller_amd.crf.basecall import compute_scores
+from xna_basecaller_amd.reads import SyntheticRead
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(features=64, labels="NACGTXY", seed=3):
+    import torch
+    model = Model(make_config(features, labels))
+    keys, shapes = encoder_shapes(features, len(labels) - 1)
+    sd = seeded_state_dict(keys, shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.eval().to("cuda"), sd
+
+
+def test_model_forward_and_decode_batch():
+    model, sd = _model()
+    x = np.random.default_rng(0).standard_normal((4, 1, 1000)).astype(np.float32)
+    scores = model(x)
+    assert scores.shape == (200, 4, 1512)
+    ref = oracle.encode(x, sd, 64, 6, 3)
+    assert np.abs(scores - ref).max() < 1e-4
+    # decode the GPU's own scores with both implementations: identical strings
+    assert model.decode_batch(scores) == oracle.decode_batch(scores, list("NACGTXY"), 3)
+
+
+def test_compute_scores_layout():
+    model, sd = _model()
+    x = np.random.default_rng(1).standard_normal((3, 1, 1000)).astype(np.float32)
+    out = compute_scores(model, x)
+    assert out["sequence"].shape == (3, 200) and out["sequence"].dtype == np.int8
+    assert out["qstring"].dtype == np.int8 and out["moves"].dtype == bool and not out["moves"].any()
+    assert np.array_equal(out["qstring"] != 0, out["sequence"] != 0)
+    assert set(np.unique(out["qstring"])) <= {0, 79}
+    # fused path == forward + decode_batch
+    seqs = model.decode_batch(model(x))
+    for i in range(3):
+        n = int((out["sequence"][i] != 0).sum())
+        assert out["sequence"][i, :n].tobytes().decode() == seqs[i]
+        assert not out["sequence"][i, n:].any()
+
+
+def test_basecall_reads_end_to_end():
+    """Mixed read lengths (shorter than a chunk, exactly one chunk, stub and no-stub multi-chunk) in input order."""
+    model, sd = _model(features=32, labels="NACGTX", seed=9)
+    L, ov, bs = 1000, 100, 7
+    rng = np.random.default_rng(4)
+    lens = [400, 1000, 1900, 2350, 2800, 5100, 999, 3700]
+    reads = [SyntheticRead("read%d" % i, rng.standard_normal(n).astype(np.float32)) for i, n in enumerate(lens)]
+    got = list(basecall(model, iter(reads), chunksize=L, overlap=ov, batchsize=bs))
+    assert [r.read_id for r, _ in got] == [r.read_id for r in reads]
+    total = mism = 0
+    for read, res in got:
+        ch = util.chunk(read.signal, L, ov)
+        sc_gpu = model(ch)
+        # exact: oracle decode of the GPU scores, packed and stitched by the same host code
+        lab = oracle.decode(sc_gpu, 5, 3)["labels"]
+        seq, qs, _ = oracle.pack(lab, "NACGTX")
+        st = util.stitch(seq, L, ov, len(read.signal), 5)
+        expect = st[st != 0].astype(np.uint8).tobytes().decode()
+        assert res["sequence"] == expect
+        assert res["qstring"] == "O" * len(expect)
+        assert res["sig_move"].shape == (util.stitch(seq, L, ov, len(read.signal), 5).size * 5,) and not res["sig_move"].any()
+        # end to end vs the all-CPU oracle (encoder differences of ~1e-5 may flip a near-tie)
+        lab2 = oracle.decode(oracle.encode(ch, sd, 32, 5, 3), 5, 3)["labels"]
+        total += lab.size
+        mism += int((lab != lab2).sum())
+    assert mism <= total // 500, (mism, total)
