@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the MI355X basecalling hot path.
+
+Metric (BASELINE.json): raw signal samples/s basecalled, chunksize 10 000.
+One "step" = one pass of the whole hot path (conv front-end -> 5 LSTM layers -> CRF linear ->
+posterior + max-plus decode -> left-packed called sequences) over one batch of synthetic chunks
+that is already resident in HBM.  Default workload = BASELINE.json configs[1]: 5-base CRF
+(labels N A C G T X), chunksize 10000, batch 512 per GPU (--nbase 6 gives configs[2]).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; every rank basecalls its own batch (reads shard, weak scaling) and the
+called sequences are gathered with ONE all_gather per step over RCCL (the path's only exchange).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+
+
+def seeded_weights(features, n_base, seed=25):
+    from conftest import encoder_shapes, seeded_state_dict
+    keys, shapes = encoder_shapes(features, n_base)
+    return seeded_state_dict(keys, shapes, seed)
+
+
+def cpu_baseline(sd, features, n_base, L, chunks, alphabet):
+    """The oracle (a port: the reference's own decode is CUDA-only) timed on this host's cores."""
+    import oracle
+    # a one-GPU box's CPU share is 16 cores; more OpenMP threads than that only adds overhead here
+    oracle.set_num_threads(min(os.cpu_count() or 1, 16))
+    x = np.random.default_rng(25).standard_normal((chunks, L)).astype(np.float32)
+    t0 = time.perf_counter()
+    sc = oracle.encode(x, sd, features, n_base, 3, expand_blanks=False)
+    lab = oracle.decode(sc, n_base, 3, blank_score=2.0)["labels"]
+    oracle.pack(lab, alphabet)
+    dt = time.perf_counter() - t0
+    return {"value": chunks * L / dt, "unit": "samples/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "%d chunks x %d samples, %d-base CRF, fp32 C oracle (OpenMP), %.1f s" % (chunks, L, n_base, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512, help="chunks per GPU per step")
+    ap.add_argument("--chunksize", type=int, default=10000)
+    ap.add_argument("--nbase", type=int, default=5, choices=[4, 5, 6])
+    ap.add_argument("--features", type=int, default=768)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--cpu-chunks", type=int, default=16, help="chunks in the bounded cpu_baseline sample (0 = skip)")
+    ap.add_argument("--lstm-mode", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from xna_basecaller_amd import _lib
+    from xna_basecaller_amd import dist as xdist
+
+    rank, world = xdist.init_from_env()
+    if world != max(args.gpus, 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    nb, L, N, F = args.nbase, args.chunksize, args.batch, args.features
+    alphabet = "NACGTXY"[:nb + 1]
+    S, E = nb ** 3, nb + 1
+    prec = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16}[args.precision]
+    ctx = _lib.Context(local, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=prec, lstm_mode=args.lstm_mode)
+    sd = seeded_weights(F, nb)
+    ctx.load_state_dict(sd)
+    T = ctx.T
+
+    # synthetic signal ~ N(0,1) generated on the device (Philox counter RNG, seeded by (25, rank)): resident in HBM
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(25 + 1000003 * rank)
+    d_signal = torch.randn((N, L), dtype=torch.float32, device=dev, generator=gen)
+    d_seq = torch.empty((N, T), dtype=torch.int8, device=dev)
+    d_len = torch.empty((N,), dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.basecall_chunks_dev(d_signal.data_ptr(), N, alphabet, d_seq.data_ptr(), d_len.data_ptr())
+        if world > 1:
+            ctx.synchronize()          # the ctx stream is not torch's: order the gather after the kernels
+            xdist.gather_packed(d_seq, d_len)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        xdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_profiling(True)
+    ctx.reset_stage_times()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as tdist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stages = ctx.stage_times()
+    ctx.set_profiling(False)
+    called = int(d_len.sum().item())
+
+    if rank != 0:
+        return
+    K = args.steps
+    samples = world * N * L * K
+    value = samples / dt
+    ms_step = 1e3 * dt / K
+
+    # ---- roofline of the dominant kernel (by device time): the LSTM recurrence -----------------------
+    # algorithmic FLOPs per launch = one layer's recurrent projection h_{t-1} W_hh^T over the launch's chunks:
+    #   LSTM = 9 437 184 FLOP per raw sample for 5 layers x (input + recurrent) projections
+    #   -> 943 718.4 FLOP per sample per recurrent projection; x (N*L) samples per launch.
+    rec_ms, rec_launches = stages["lstm_rec"]
+    flop_launch = 2.0 * (4 * F) * F * T * N
+    rec_avg_s = 1e-3 * rec_ms / max(rec_launches, 1)
+    rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
+    roofline = {"kernel": "lstm_kernel<%d,%d>" % (F // 16, 3 if prec == 0 else 1), "bound": "mfma",
+                "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches,
+                "note": "algorithmic fp32-equivalent FLOPs; the split-fp16 path issues 3 MFMA products per FLOP pair"}
+    # ---- CRF decode: HBM roofline (the north-star target) -------------------------------------------------
+    dec_ms, dec_launches = stages["decode"]
+    a_dec = float(T) * N * (3 * S * E * 4 + 7 * S * 4 + 1)        # A_dec bytes per launch
+    dec_avg_s = 1e-3 * dec_ms / max(dec_launches, 1)
+    dec_gbs = a_dec / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
+    roofline_decode = {"kernel": "crf_decode_kernel", "bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": None,
+                       "avg_launch_ms": 1e3 * dec_avg_s, "launches": dec_launches,
+                       "decode_only_samples_per_s": N * L / dec_avg_s if dec_avg_s > 0 else 0.0}
+
+    out = {
+        "metric": "raw signal samples/sec basecalled, chunksize 10k", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (split-f16x3 MFMA, f32 accumulate; CRF decode f32)" if prec == 0 else "f16 MFMA, f32 accumulate; CRF decode f32",
+        "data": "synthetic N(0,1) signal chunks generated in HBM; seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout",
+        "config": {"workload": "BASELINE configs[%d]: %d-base CRF (S=%d, C=%d), chunksize %d, batch %d per GPU, features %d"
+                               % (1 if nb == 5 else 2, nb, S, S * E, L, N, F),
+                   "n_base": nb, "chunksize": L, "batch_per_gpu": N, "T": T, "parallelism": "reads sharded x%d" % world,
+                   "collective": "all_gather of packed sequences per step" if world > 1 else "none"},
+        "roofline": roofline, "roofline_decode": roofline_decode,
+        "stage_ms_per_step": {k: v[0] / K for k, v in stages.items()},
+        "called_bases_last_step": called,
+    }
+    if world == 1 and args.cpu_chunks > 0:
+        out["cpu_baseline"] = cpu_baseline(sd, F, nb, L, args.cpu_chunks, alphabet)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,7 @@ from .oracle import (  # noqa: F401
     expf,
     logf,
     num_threads,
+    set_num_threads,
     STATE_DICT_ORDER,
     state_dict_list,
 )

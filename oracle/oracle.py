@@ -60,6 +60,10 @@ def num_threads():
     return int(lib().xo_num_threads())
 
 
+def set_num_threads(n):
+    lib().xo_set_num_threads(C.c_int(int(n)))
+
+
 def expf(x):
     x = _f32(x)
     y = np.empty_like(x)

@@ -349,34 +349,41 @@ XO_API void xo_conv1d_silu(const float *x, int N, int Cin, int L, const float *w
         }
 }
 
-/* C(M,Nn) = A(M,K) * B(Nn,K)^T + bias(Nn) ; row-major, B given as [out][in] (torch layout). */
+/* C(M,Nn) = A(M,K) * B(Nn,K)^T + bias(Nn) ; row-major, B given as [out][in] (torch layout).
+ * Work is split over (row block, column block) so that the small-M recurrent products use all cores. */
+static inline float dot8(const float *ap, const float *bp, int K)
+{
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        s0 += ap[k] * bp[k];         s1 += ap[k + 1] * bp[k + 1];
+        s2 += ap[k + 2] * bp[k + 2]; s3 += ap[k + 3] * bp[k + 3];
+        s4 += ap[k + 4] * bp[k + 4]; s5 += ap[k + 5] * bp[k + 5];
+        s6 += ap[k + 6] * bp[k + 6]; s7 += ap[k + 7] * bp[k + 7];
+    }
+    float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    for (; k < K; ++k) s += ap[k] * bp[k];
+    return s;
+}
+
 static void gemm_nt_bias(const float *A, const float *B, const float *bias, float *C,
                          int64_t M, int Nn, int K)
 {
-#pragma omp parallel for schedule(static)
-    for (int64_t m0 = 0; m0 < M; m0 += 8) {
-        const int64_t mb = (M - m0) < 8 ? (M - m0) : 8;
-        for (int n0 = 0; n0 < Nn; ++n0) {
-            const float *bp = B + (size_t)n0 * K;
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int64_t mi = 0; mi < mb; ++mi) {
-                const float *ap = A + (size_t)(m0 + mi) * K;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-                int k = 0;
-                for (; k + 8 <= K; k += 8) {
-                    s0 += ap[k] * bp[k];         s1 += ap[k + 1] * bp[k + 1];
-                    s2 += ap[k + 2] * bp[k + 2]; s3 += ap[k + 3] * bp[k + 3];
-                    s4 += ap[k + 4] * bp[k + 4]; s5 += ap[k + 5] * bp[k + 5];
-                    s6 += ap[k + 6] * bp[k + 6]; s7 += ap[k + 7] * bp[k + 7];
-                }
-                float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-                for (; k < K; ++k) s += ap[k] * bp[k];
-                acc[mi] = s;
+    const int MB = 16, NB = 32;
+    const int64_t mblocks = (M + MB - 1) / MB;
+    const int nblocks = (Nn + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t mb = 0; mb < mblocks; ++mb)
+        for (int nbk = 0; nbk < nblocks; ++nbk) {
+            const int64_t m0 = mb * MB, m1 = (m0 + MB < M) ? m0 + MB : M;
+            const int n0 = nbk * NB, n1 = (n0 + NB < Nn) ? n0 + NB : Nn;
+            for (int n = n0; n < n1; ++n) {
+                const float *bp = B + (size_t)n * K;
+                const float bv = bias ? bias[n] : 0.0f;
+                for (int64_t m = m0; m < m1; ++m)
+                    C[(size_t)m * Nn + n] = dot8(A + (size_t)m * K, bp, K) + bv;
             }
-            for (int64_t mi = 0; mi < mb; ++mi)
-                C[(size_t)(m0 + mi) * Nn + n0] = acc[mi] + (bias ? bias[n0] : 0.0f);
         }
-    }
 }
 
 /*
@@ -495,6 +502,15 @@ XO_API int xo_encode(const float *signal, int N, int L, const float *const *weig
 done:
     free(c1); free(c2); free(c3); free(xa); free(xb);
     return rc;
+}
+
+XO_API void xo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 XO_API int xo_num_threads(void)
