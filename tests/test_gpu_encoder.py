@@ -99,3 +99,25 @@ def test_encoder_fp16_fast_mode_is_close():
     got = ctx.encode(signal[:, 0, :])
     assert np.abs(got - ref).max() < 2e-2
     ctx.close()
+
+
+def test_persistent_handoff_is_placement_independent(monkeypatch):
+    """Full-size W (features 768, 24 member workgroups per group), several groups, ragged last group:
+    the persistent kernel must equal the one-launch-per-step kernel bit for bit, both with a group's members
+    on one XCD (default block mapping) and spread over all XCDs (XB_LSTM_SPREAD=1)."""
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))["full"]
+    sd = seeded_state_dict(meta["keys"], meta["shapes"], meta["seed"])
+    N, L = 150, 400
+    x = np.random.default_rng(11).standard_normal((N, L)).astype(np.float32)
+    outs = {}
+    for name, mode, spread in [("step", 1, "0"), ("persist", 2, "0"), ("persist_spread", 2, "1")]:
+        monkeypatch.setenv("XB_LSTM_SPREAD", spread)
+        ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, L, N, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        for rep in range(3 if mode == 2 else 1):           # repeated launches reuse warm caches
+            outs[name] = ctx.encode(x)
+        ctx.close()
+    assert np.array_equal(outs["step"], outs["persist"])
+    assert np.array_equal(outs["step"], outs["persist_spread"])
+    ref = oracle.encode(x[:4], sd, 768, 6, 3)
+    assert np.abs(outs["persist"][:, :4] - ref).max() < 1e-4

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxnacall.so")
+LIB_PATH = os.environ.get("XNA_LIBXNACALL", os.path.join(_HERE, "libxnacall.so"))   # override: diagnostic builds only
 _lib = None
 
 XB_STAGE_NAMES = ("conv", "lstm_in", "lstm_rec", "linear", "decode")

@@ -56,6 +56,7 @@ struct xb_ctx {
     half_t *im_hi = nullptr, *im_lo = nullptr;
     half_t *x_hi[2] = {}, *x_lo[2] = {};
     float *gin = nullptr, *c_state = nullptr, *scores = nullptr;
+    half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
     float *alpha = nullptr, *beta = nullptr, *bmax = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
     int32_t *seq_len = nullptr;
@@ -221,9 +222,10 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const ha
     XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));
     xb::LstmParams p{};
     p.gin = ctx->gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
-    p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state;
+    p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state; p.xh = ctx->xh;
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
     p.sync = ctx->sync; p.error = ctx->error; p.nsplit = nsplit;
+    if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
     if (mode == 2) {
         const int slab = gmax > 64 ? 64 * bn : gmax * bn;
         int launches = 0;
@@ -388,6 +390,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     }
     rc = rc ? rc : dev_alloc(ctx, &ctx->gin, T * N * 4 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
     rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
@@ -617,5 +620,16 @@ XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_n
     if (C_noblank) *C_noblank = ctx->O;
     return XB_OK;
 }
+
+#ifdef XB_LSTM_STAMPS
+// diagnostic build only (csrc/Makefile target `diag`): per-phase cycle sums of the LSTM kernel's workgroup 0
+XB_API int xb_debug_lstm_stamps(xb_ctx *ctx, unsigned long long out[8], int reset)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    xb::lstm_read_stamps(out, reset != 0);
+    return XB_OK;
+}
+#endif
 
 }  // extern "C"

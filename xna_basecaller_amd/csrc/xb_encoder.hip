@@ -21,12 +21,13 @@ using xb::half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x)
 {
     // 1 - 2/(e^{2x}+1); exact limits at +-inf, abs error ~1e-7
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    return 1.0f - 2.0f * fast_rcp(e + 1.0f);
 }
 __device__ __forceinline__ float silu(float x) { return x * fast_sigmoid(x); }
 
@@ -259,24 +260,51 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(xb::GemmParams p)
 // A *group* = LG_BN chunks; its F/32 member workgroups each own 32 hidden units (128
 // gate-interleaved rows of W_hh: wave w holds rows [32w, 32w+32) = units 8w..8w+7 as MFMA
 // A-operand fragments in registers for the whole launch).  Per step a member needs the whole
-// h_{t-1} of its group's chunks: it is pulled from the layer output buffer (the members'
-// previous-step stores) into LDS by LDS-DMA in K pieces of KP columns, double buffered against
-// the MFMAs.  MFMA tile orientation: rows = gate rows (so one lane owns i,f,g,o of a unit in
-// four consecutive accumulator registers), columns = chunks.
-// persistent = 1: all steps in one launch; members of a group meet after every step on a
-// monotonic arrival counter (plain stores -> every wave vmcnt(0) -> barrier -> one lane:
-// agent release fence, vmcnt(0), relaxed agent atomic add; consumer: one lane polls relaxed,
-// agent acquire fence, vmcnt(0), barrier, then loads).  Every spin is bounded.
+// h_{t-1} of its group's chunks.  The members exchange h through a small ping-pong buffer
+// xh[parity][group][part][64 chunks][F] (a few MB, L2/Infinity-Cache resident) and, beside it,
+// write the layer output y (T,N,F) that the next layer consumes after the launch.
+// The exchange rows are pulled into LDS by LDS-DMA in K pieces of KP columns, double buffered
+// against the MFMAs, B fragments software-pipelined one k-step ahead.
+// MFMA tile orientation: rows = gate rows (one lane owns i,f,g,o of a unit in four consecutive
+// accumulator registers), columns = chunks.
+// persistent = 1: all steps in one launch.  Hand-off protocol per step (cdna_hip_programming.md
+// Guideline 16, form R1): exchange stores are 16-byte write-through (sc1) stores; every storing
+// wave drains them (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds to the group's
+// monotonic agent-scope counter.  Consumer: ONE lane polls that counter with relaxed sc1 loads
+// (bounded spin), workgroup barrier, then EVERY load of the exchanged bytes is an sc1 load
+// (LDS-DMA with the sc1 bit), so no L1 line can be stale and no fence is needed.
 // ======================================================================================
 constexpr int LG_BN = 64;        // chunks per group (2 MFMA column tiles)
 constexpr int LG_UNITS = 32;     // hidden units per member workgroup
 constexpr unsigned long long LG_SPIN_CYCLES = 4000000000ull;   // ~2 s at 2 GHz
+constexpr int CPOL_SC1 = 16;     // gfx940+ cache-policy immediate: sc0 = 1, nt = 2, sc1 = 16
 
-__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
+__device__ __forceinline__ void dma16_sc1(const void *g, void *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, CPOL_SC1);
 }
+
+// 16-byte write-through store (the `s_nop 1` keeps the data registers intact until the store has read them)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(void *g, uint4 v)
+{
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(d) : "memory");
+}
+
+#ifdef XB_LSTM_STAMPS
+// diagnostic build only: per-phase cycle sums of workgroup 0 (never compiled into the product)
+__device__ unsigned long long g_lstm_stamps[8];
+#define XB_STAMP(i)                                                                         \
+    do {                                                                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter();                       \
+        if (blockIdx.x == 0 && tid == 0) g_lstm_stamps[(i)] += now_ - stamp_prev;            \
+        stamp_prev = now_;                                                                  \
+    } while (0)
+#else
+#define XB_STAMP(i) do { } while (0)
+#endif
 
 template <int KS, int NSPLIT>
 __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
@@ -294,13 +322,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
     half_t *sT = reinterpret_cast<half_t *>(smem_raw + 2 * NPARTS * PIECE_BYTES); // [NPARTS][64][32]
-    int *sFlag = reinterpret_cast<int *>(sT + NPARTS * LG_BN * LG_UNITS);
+    float *sC = reinterpret_cast<float *>(sT + NPARTS * LG_BN * LG_UNITS);          // [32 units][64 chunks] cell state
+    int *sFlag = reinterpret_cast<int *>(sC + LG_UNITS * LG_BN);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int members = F / LG_UNITS;
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const int g8 = (ngroups + 7) & ~7;
-    const int grp = blockIdx.x % g8, mb = blockIdx.x / g8;
+    // default: blocks b, b+8, b+16.. (one XCD under round-robin dispatch) form a group -- speed only.
+    // spread = 1 deals a group's members over consecutive blocks, i.e. over all XCDs (placement test).
+    const int grp = p.spread ? (int)blockIdx.x / members : (int)blockIdx.x % g8;
+    const int mb = p.spread ? (int)blockIdx.x % members : (int)blockIdx.x / g8;
     if (grp >= ngroups) return;
     const int N = p.N, T = p.T;
     const int nlast = p.n0 + p.nslab - 1;
@@ -319,24 +352,30 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
     }
 
-    // ---- cell state: lane owns (chunk = 32*nt + (l&31), unit = ubase + 2*rg + hsel)
-    float c[2][4];
+    // ---- cell state lives in LDS as [unit][chunk] (the register file is full of W_hh): lane owns
+    //      (chunk = 32*nt + (l&31), unit = 8*wid + 2*rg + hsel), only ever touched by that lane
     int chunk[2];
-    bool cvalid[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = cbase + nt * 32 + (lane & 31);
-        cvalid[nt] = n <= nlast;
-        chunk[nt] = cvalid[nt] ? n : nlast;
+        chunk[nt] = n <= nlast ? n : nlast;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) c[nt][rg] = p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel];
+        for (int rg = 0; rg < 4; ++rg)
+            sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)] =
+                p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel];
     }
 
     unsigned *cnt = p.sync + (size_t)grp * 32;
+    // exchange buffer of this group: [parity][part][64 rows][F]
+    half_t *xg = p.xh + (size_t)grp * (2 * 2 * LG_BN * F);
+    constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
 
+#ifdef XB_LSTM_STAMPS
+    unsigned long long stamp_prev = __builtin_readcyclecounter();
+#endif
     for (int s = p.s_begin; s < p.s_end; ++s) {
+        XB_STAMP(0);   // loop overhead / y stores of the previous step
         const int t = p.reverse ? T - 1 - s : s;
-        const int tprev = p.reverse ? t + 1 : t - 1;
 
         // accumulators start from the input projection (+ biases)
         floatx16 acc[2];
@@ -359,7 +398,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const unsigned long long t0 = __builtin_readcyclecounter();
                     int ok = 1;
                     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                         if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                             __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES) {
                             __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -367,55 +406,84 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             break;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     *sFlag = ok;
                 }
                 __syncthreads();
                 if (*sFlag == 0) return;
             }
+            XB_STAMP(1);   // gin loads issued + wait for the group
 
-            // h_{t-1} of the group's chunks, piece by piece through LDS
-            auto issue_piece = [&](int pc) {
-                unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
-                // CPR wave-instructions per part; wave w issues q = w, w+4, ...
-#pragma unroll
-                for (int part = 0; part < NPARTS; ++part) {
-                    const half_t *y = part == 0 ? p.y_hi : p.y_lo;
-                    for (int q = wid; q < CPR; q += 4) {
-                        const int cell = 64 * q + lane;
-                        const int row = cell / CPR, pos = cell % CPR;
-                        const int kc = pos ^ (row & SWZ);
-                        int n = cbase + row;
-                        n = n > nlast ? nlast : n;
-                        const half_t *src = y + ((size_t)tprev * N + n) * F + pc * KP + kc * 8;
-                        dma16(src, buf + part * PIECE_BYTES + q * 1024);
-                    }
+            // h_{t-1} of the group's chunks, piece by piece through LDS (every load sc1).
+            // A piece is NPARTS * CPR wave-instructions of 1 KiB; wave w issues NDMA = NPARTS * CPR / 4 of
+            // them (q = w, w+4, ..), exactly one per MFMA k-step when NSPLIT == 3, so the next piece's
+            // DMA is issued in the shadow of this piece's MFMAs instead of in front of them.
+            constexpr int NDMA = NPARTS * CPR / 4;
+            const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;
+            // instruction q covers cells [64q, 64q+64) = rows RPI*q .. of CPR cells.  For power-of-two CPR the
+            // per-lane part of the source offset is the same for every q of a wave (q = wid mod 4 and
+            // RPI*4 = 0 mod CPR), so it is ONE register; everything else is wave-uniform scalar arithmetic.
+            constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+            constexpr int RPI = 64 / (POW2 ? CPR : 1);
+            const int lrow = lane / CPR;
+            const int lane_off = POW2 ? lrow * F + (((lane % CPR) ^ ((RPI * wid + lrow) & SWZ)) * 8) : 0;
+            auto issue_dma = [&](int pc, int d) {
+                const int part = NPARTS == 2 ? (d & 1) : 0;
+                const int q = wid + 4 * (NPARTS == 2 ? (d >> 1) : d);
+                unsigned char *dst = sPiece + (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + q * 1024;
+                if (POW2) {
+                    const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
+                    dma16_sc1(base + lane_off, dst);
+                } else {
+                    const int cell = 64 * q + lane;
+                    const int row = cell / CPR, pos = cell % CPR;
+                    dma16_sc1(xprev + part * XPART + (size_t)row * F + pc * KP + (pos ^ (row & SWZ)) * 8, dst);
                 }
             };
-            issue_piece(0);
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) issue_dma(0, d);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            XB_STAMP(2);   // first piece landed
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
-                if (pc + 1 < NP) issue_piece(pc + 1);
                 const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
-#pragma unroll
-                for (int ks = 0; ks < KSP; ++ks) {
-                    const int kg = pc * KSP + ks;
+                // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
+                // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use)
+                half8 fh[2][2], fl[2][2];
+                auto load_frags = [&](int ks, half8 (&h)[2], half8 (&l)[2]) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         const int row = nt * 32 + (lane & 31);
                         const int pos = (2 * ks + hsel) ^ (row & SWZ);
-                        const half8 bh = *reinterpret_cast<const half8 *>(buf + (row * CPR + pos) * 16);
-                        if (NSPLIT == 3) {
-                            const half8 bl = *reinterpret_cast<const half8 *>(buf + PIECE_BYTES + (row * CPR + pos) * 16);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kg], bh, acc[nt], 0, 0, 0);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], bl, acc[nt], 0, 0, 0);
-                        }
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], bh, acc[nt], 0, 0, 0);
+                        h[nt] = *reinterpret_cast<const half8 *>(buf + (row * CPR + pos) * 16);
+                        if (NSPLIT == 3) l[nt] = *reinterpret_cast<const half8 *>(buf + PIECE_BYTES + (row * CPR + pos) * 16);
                     }
+                };
+                load_frags(0, fh[0], fl[0]);
+#pragma unroll
+                for (int ks = 0; ks < KSP; ++ks) {
+                    const int kg = pc * KSP + ks;
+                    if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (NSPLIT == 3) {
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fl[ks & 1][nt], acc[nt], 0, 0, 0);
+                        }
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                    }
+                    // two per k-step so that the last one is issued by mid-piece and has landed at the barrier
+                    if (pc + 1 < NP) {
+                        if (2 * ks < NDMA) issue_dma(pc + 1, 2 * ks);
+                        if (2 * ks + 1 < NDMA) issue_dma(pc + 1, 2 * ks + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
                 __syncthreads();
+                XB_STAMP(7);   // piece DMA wait + barrier
             }
         }
 
@@ -428,8 +496,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 const float fg = fast_sigmoid(acc[nt][4 * rg + 1]);
                 const float gg = fast_tanh(acc[nt][4 * rg + 2]);
                 const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
-                const float cn = fg * c[nt][rg] + ig * gg;
-                c[nt][rg] = cn;
+                float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
+                const float cn = fg * *cp + ig * gg;
+                *cp = cn;
                 const float hv = og * fast_tanh(cn);
                 half_t hi, lo;
                 split_f16(hv, hi, lo);
@@ -439,37 +508,45 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             }
         __syncthreads();
         // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part
-        {
-            const int row = tid >> 2, cc = tid & 3;
-            const int n = cbase + row;
-            if (n <= nlast) {
-                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + cc * 8;
-                *reinterpret_cast<uint4 *>(p.y_hi + o) = *reinterpret_cast<const uint4 *>(sT + row * LG_UNITS + cc * 8);
-                if (NSPLIT == 3)
-                    *reinterpret_cast<uint4 *>(p.y_lo + o) =
-                        *reinterpret_cast<const uint4 *>(sT + LG_BN * LG_UNITS + row * LG_UNITS + cc * 8);
-                else
-                    *reinterpret_cast<uint4 *>(p.y_lo + o) = make_uint4(0, 0, 0, 0);
-            }
+        const int orow = tid >> 2, occ = tid & 3;
+        const uint4 vhi = *reinterpret_cast<const uint4 *>(sT + orow * LG_UNITS + occ * 8);
+        uint4 vlo = make_uint4(0, 0, 0, 0);
+        if (NSPLIT == 3) vlo = *reinterpret_cast<const uint4 *>(sT + LG_BN * LG_UNITS + orow * LG_UNITS + occ * 8);
+        const bool more = s + 1 < p.s_end || !p.persistent;
+        if (more && s + 1 < T) {
+            // publish h_t for the group (rows beyond the slab are scratch rows of the exchange buffer)
+            half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
+            store16_sc1(xcur, vhi);
+            if (NSPLIT == 3) store16_sc1(xcur + XPART, vlo);
         }
+        XB_STAMP(4);   // pointwise + exchange stores issued
         if (p.persistent && s + 1 < p.s_end) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
             __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            XB_STAMP(5);   // stores drained
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            XB_STAMP(6);   // arrive
         } else {
             __syncthreads();   // sT is rewritten next step
+        }
+        // layer output for the next layer: plain stores, nobody in this launch reads them
+        {
+            const int n = cbase + orow;
+            if (n <= nlast) {
+                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + occ * 8;
+                *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
+                *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+            }
         }
     }
 
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
-        if (cvalid[nt])
+        if (cbase + nt * 32 + (lane & 31) <= nlast)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel] = c[nt][rg];
+            for (int rg = 0; rg < 4; ++rg)
+                p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel] =
+                    sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)];
 }
 
 template <int KS>
@@ -481,7 +558,8 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const int g8 = (ngroups + 7) & ~7;
     const int members = F / LG_UNITS;
-    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * LG_BN * LG_UNITS * 2 + 16;
+    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * LG_BN * LG_UNITS * 2 +
+                       sizeof(float) * LG_UNITS * LG_BN + 16;
     dim3 grid(g8 * members), block(256);
     if (p.nsplit == 3)
         hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
@@ -529,6 +607,17 @@ hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream)
     default: return hipErrorInvalidValue;
     }
 }
+
+#ifdef XB_LSTM_STAMPS
+void lstm_read_stamps(unsigned long long out[8], bool reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_stamps), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamps), z, sizeof z);
+    }
+}
+#endif
 
 bool lstm_supported_features(int F)
 {

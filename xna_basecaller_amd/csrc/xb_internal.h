@@ -61,6 +61,7 @@ struct LstmParams {
     const half_t *w_hi, *w_lo;   // (4F, F) gate-interleaved rows
     half_t *y_hi, *y_lo;         // (T, N, F)
     float *c_state;              // (N, F) fp32 cell state (in/out across launches)
+    half_t *xh;                  // exchange buffer [groups][2 parity][2 parts][64][F] (h of the previous step)
     int T, N, F;
     int n0, nslab;               // chunks [n0, n0+nslab) are processed by this launch
     int reverse;                 // time runs T-1..0
@@ -69,11 +70,15 @@ struct LstmParams {
     unsigned *sync;              // per-group arrival counters (zeroed before a persistent launch), stride 32 words
     unsigned *error;             // set non-zero when a sync wait timed out
     int nsplit;
+    int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
 int lstm_members(int F);
 int lstm_group_chunks();
 bool lstm_supported_features(int F);
+#ifdef XB_LSTM_STAMPS
+void lstm_read_stamps(unsigned long long out[8], bool reset);   // diagnostic build only
+#endif
 
 }  // namespace xb
