@@ -81,6 +81,15 @@ __device__ __forceinline__ float xb_logf(float x)
 
 __device__ __forceinline__ float maxf(float a, float b) { return b > a ? b : a; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. emits
+// s_waitcnt vmcnt(0), which would drain the score prefetch ring (a full HBM latency) at every time step.
+// Inside the sweeps the only cross-thread data is in LDS; the global stashes are re-read by the thread that
+// wrote them (and the sweeps are separated by real __syncthreads()).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int VW> struct VecT;
 template <> struct VecT<1> { using type = float; };
 // native clang vectors (HIP's float2/float4 wrapper structs defeat scalar replacement in arrays)
@@ -89,8 +98,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<4> { using type = f32x4; };
 
-// Score row of one (t, chunk): `cin` floats at row pointer; staged into LDS by all BS threads in
-// groups of VW floats.  NR = groups per thread.
+// ---- explicit prefetch control ------------------------------------------------------------------
+// hipcc's s_waitcnt insertion loses the in-order vmcnt arithmetic across the loop's control flow and waits
+// vmcnt(0/1) before every use of the ring, i.e. drains the whole prefetch each step.  Every global LOAD inside
+// the sweeps is therefore an inline-asm load the compiler does not track, and each ring slot is consumed behind
+// a hand-counted s_waitcnt vmcnt(N): N = (DEPTH-1) * (loads issued per step).  Stores issued in between also
+// count on vmcnt, in order, so ignoring them only makes the wait longer, never too short.
+__device__ __forceinline__ void ld_asm(float &d, const float *p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void ld_asm(f32x2 &d, const float *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void ld_asm(f32x4 &d, const float *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// makes `x` opaque at this point: no use of x may be scheduled above a preceding wait_vm
+template <typename Tp> __device__ __forceinline__ void pin(Tp &x) { asm volatile("" : "+v"(x)); }
+
+// Score row of one (t, chunk): `cin` floats at the row pointer; all BS threads move groups of VW floats
+// (NR groups per thread).  Loads are unconditional: out-of-range groups re-read group 0 and are parked in the
+// padding of the LDS buffer (BS*NR*VW floats), so the memory part of the loop is branch-free.
 template <int VW, int NR, int BS>
 struct ScoreRing {
     using V = typename VecT<VW>::type;
@@ -99,18 +122,16 @@ struct ScoreRing {
     {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            // out-of-range groups re-read group 0 (always valid) instead of predicating the load:
-            // keeps the ring in registers; the LDS store below is what is guarded
             const int g = (tid + BS * i) * VW;
-            r[i] = *reinterpret_cast<const V *>(row + (g < cin ? g : 0));
+            ld_asm(r[i], row + (g < cin ? g : 0));
         }
     }
-    __device__ __forceinline__ void store(float *lds, int cin, int tid) const
+    __device__ __forceinline__ void store(float *lds, int tid)
     {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int g = (tid + BS * i) * VW;
-            if (g < cin) *reinterpret_cast<V *>(lds + g) = r[i];
+            pin(r[i]);
+            *reinterpret_cast<V *>(lds + (tid + BS * i) * VW) = r[i];
         }
     }
 };
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
     const bool act = tid < S;
-    const int cpad = (cin + 3) & ~3;
+    constexpr int cpad = BS * NR * VW;           // staging row incl. parking space for out-of-range groups
 
     float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]
     float *sA = sM + 2 * cpad;                                    // [2][S]  alpha / beta
@@ -157,22 +178,26 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     const float blank = p.blank;
 
     ScoreRing<VW, NR, BS> ring[DEPTH];
+    const int stid = act ? tid : S - 1;          // stash column read by this thread (clamped, always valid)
 
     // ------------------------------------------------------------------ sweep 1: Log forward
     if (act) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (d < T) ring[d].load(sc + (size_t)d * tstride, cin, tid);
+    for (int d = 0; d < DEPTH; ++d) ring[d].load(sc + (size_t)(d < T ? d : T - 1) * tstride, cin, tid);
 
     for (int t0 = 0; t0 < T; t0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int t = t0 + d;
-            if (t < T) {
+            if (t < T) {                                   // wave-uniform
                 float *m = sM + (t & 1) * cpad;
-                ring[d].store(m, cin, tid);
-                if (t + DEPTH < T) ring[d].load(sc + (size_t)(t + DEPTH) * tstride, cin, tid);
-                __syncthreads();
+                wait_vm<(DEPTH - 1) * NR>();
+                ring[d].store(m, tid);
+                {
+                    const int tn = t + DEPTH < T ? t + DEPTH : T - 1;
+                    ring[d].load(sc + (size_t)tn * tstride, cin, tid);
+                }
+                lds_barrier();
                 if (act) {
                     const float *a0 = sA + (t & 1) * S;
                     const int j = tid;
@@ -195,6 +220,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             }
         }
     }
+    wait_vm<0>();
     __syncthreads();
 
     // logZ = logsumexp_j alpha_T[j], summed in order j = 0..S-1
@@ -231,11 +257,9 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         }
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const int t = T - 1 - d;
-            if (t >= 0) {
-                ring[d].load(sc + (size_t)t * tstride, cin, tid);
-                if (act) aring[d] = alpha[(size_t)t * sstride + tid];
-            }
+            const int t = T - 1 - d >= 0 ? T - 1 - d : 0;
+            ring[d].load(sc + (size_t)t * tstride, cin, tid);
+            ld_asm(aring[d], alpha + (size_t)t * sstride + stid);
         }
         const int i = tid;
         const int kk = i / hi + 1;
@@ -246,13 +270,16 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 const int t = T - 1 - (s0 + d);
                 if (t >= 0) {
                     float *m = sM + (t & 1) * cpad;
-                    ring[d].store(m, cin, tid);
+                    wait_vm<(DEPTH - 1) * (NR + 1)>();
+                    ring[d].store(m, tid);
+                    pin(aring[d]);
                     const float a0 = aring[d];
-                    if (t - DEPTH >= 0) {
-                        ring[d].load(sc + (size_t)(t - DEPTH) * tstride, cin, tid);
-                        if (act) aring[d] = alpha[(size_t)(t - DEPTH) * sstride + tid];
+                    {
+                        const int tn = t - DEPTH >= 0 ? t - DEPTH : 0;
+                        ring[d].load(sc + (size_t)tn * tstride, cin, tid);
+                        ld_asm(aring[d], alpha + (size_t)tn * sstride + stid);
                     }
-                    __syncthreads();
+                    lds_barrier();
                     if (act) {
                         const float *b1 = sA + ((t + 1) & 1) * S;
                         const float *m1 = sX + ((t + 1) & 1) * S;
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 }
             }
         }
+        wait_vm<0>();
         __syncthreads();
     }
 
@@ -302,14 +330,11 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         if (act) sX[tid] = 0.0f;
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (d < T) {
-                ring[d].load(sc + (size_t)d * tstride, cin, tid);
-                if (act) {
-                    aring[d] = alpha[(size_t)d * sstride + tid];
-                    bring[d] = beta[(size_t)(d + 1) * sstride + tid];
-                    mring[d] = bmax[(size_t)(d + 1) * sstride + tid];
-                }
-            }
+            const int t = d < T ? d : T - 1;
+            ring[d].load(sc + (size_t)t * tstride, cin, tid);
+            ld_asm(aring[d], alpha + (size_t)t * sstride + stid);
+            ld_asm(bring[d], beta + (size_t)(t + 1) * sstride + stid);
+            ld_asm(mring[d], bmax + (size_t)(t + 1) * sstride + stid);
         }
         const int j = tid;
         const int jq = j / NB;
@@ -320,18 +345,19 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 const int t = t0 + d;
                 if (t < T) {
                     float *m = sM + (t & 1) * cpad;
-                    ring[d].store(m, cin, tid);
+                    wait_vm<(DEPTH - 1) * (NR + 3)>();
+                    ring[d].store(m, tid);
+                    pin(aring[d]); pin(bring[d]); pin(mring[d]);
                     if (act) sG[(t & 1) * S + j] = aring[d];
                     const float b1j = bring[d], m1j = mring[d];
-                    if (t + DEPTH < T) {
-                        ring[d].load(sc + (size_t)(t + DEPTH) * tstride, cin, tid);
-                        if (act) {
-                            aring[d] = alpha[(size_t)(t + DEPTH) * sstride + tid];
-                            bring[d] = beta[(size_t)(t + DEPTH + 1) * sstride + tid];
-                            mring[d] = bmax[(size_t)(t + DEPTH + 1) * sstride + tid];
-                        }
+                    {
+                        const int tn = t + DEPTH < T ? t + DEPTH : T - 1;
+                        ring[d].load(sc + (size_t)tn * tstride, cin, tid);
+                        ld_asm(aring[d], alpha + (size_t)tn * sstride + stid);
+                        ld_asm(bring[d], beta + (size_t)(tn + 1) * sstride + stid);
+                        ld_asm(mring[d], bmax + (size_t)(tn + 1) * sstride + stid);
                     }
-                    __syncthreads();
+                    lds_barrier();
                     // finalise the previous step's arg-max (partials were written before this barrier)
                     if (tid == 0 && t > 0) {
                         const float *rv = sRv + ((t - 1) & 1) * (BS / 64);
@@ -382,6 +408,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 }
             }
         }
+        wait_vm<0>();
         __syncthreads();
         if (tid == 0) {
             const float *rv = sRv + ((T - 1) & 1) * (BS / 64);
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     if (p.labels)
         for (int t = tid; t < T; t += BS) p.labels[(size_t)n * T + t] = sLab[t];
     if (p.seq || p.seq_len) {
-        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints, sM is free now (cpad*2 >= BS+1 checked on host)
+        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints, sM (2*BS*NR*VW floats) is free now
         const int per = (T + BS - 1) / BS;
         const int lo = tid * per, hiT = (lo + per < T) ? lo + per : T;
         int cnt = 0;
@@ -428,7 +455,9 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 template <int NB, int BS>
 hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    const int cpad = (p.cin + 3) & ~3;
+    constexpr int E = NB + 1;
+    const int nr = (E + vw - 1) / vw;
+    const int cpad = BS * nr * vw;
     size_t lds = sizeof(float) * (2 * (size_t)cpad + 6 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
                  sizeof(float) * 4 + (size_t)p.T;
     lds = (lds + 15) & ~(size_t)15;
@@ -457,14 +486,14 @@ hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 namespace xb {
 
 // Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:
-//   S = NB^state_len <= 1024, cin = S*(NB+1) or S*NB, ld >= cin, 2*cpad >= BS+1 (pack scratch).
+//   S = NB^state_len <= 1024, cin = S*(NB+1) or S*NB, ld >= cin (the pack scratch of BS+1 ints always
+//   fits the 2*BS*NR*VW-float staging area).
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
 {
     if (p.S < 1 || p.S > 1024 || p.T < 1 || p.N < 1) return hipErrorInvalidValue;
     const int E = p.nb + 1;
     if (p.cin != (p.has_blank ? p.S * E : p.S * p.nb) || p.ld < p.cin) return hipErrorInvalidValue;
     const int bs = p.S <= 64 ? 64 : p.S <= 128 ? 128 : p.S <= 256 ? 256 : 1024;
-    if (2 * ((p.cin + 3) & ~3) < bs + 1) return hipErrorInvalidValue;
     int vw = 1;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p.scores);
     // vector loads may run into the row's padding columns (ld >= cin rounded up), never past the row

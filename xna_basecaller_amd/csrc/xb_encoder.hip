@@ -115,21 +115,26 @@ __global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
 
 // ======================================================================================
 // split-fp16 MFMA GEMM:  D[m][n] = sum_k A[m][k] B[n][k]
-// 128x128 tile, BK = 32, 4 waves (2x2), each 64x64 = 2x2 MFMA 32x32x16 tiles.
-// LDS image per operand part: [128 rows][4 cells of 16 B], cell index XOR-swizzled with
+// 256x256 block tile, BK = 32, 8 waves (2 in M x 4 in N), each wave 128x64 = 4x2 MFMA 32x32x16
+// tiles, three products per tile pair (lo*hi, hi*lo, hi*hi).  Per 16-deep k-step a wave reads
+// (4 + 2) fragments x (hi, lo) = 12 KiB from LDS for 24 MFMAs, which keeps the LDS read path at
+// about half of its peak with all 8 waves running (a 128x128 tile saturated it).
+// LDS image per operand part: [256 rows][4 cells of 16 B], cell index XOR-swizzled with
 // (row >> 2) & 3 so that every 16-lane ds_read_b128 group hits 16 distinct bank slots.
+// Register-staged double buffering: global loads of tile k+1 are in flight during the MFMAs of
+// tile k and are written to the other LDS stage afterwards; one barrier per tile.
 // ======================================================================================
-constexpr int GT = 128, GBK = 32;
+constexpr int GBM = 256, GBN = 256, GBK = 32, GTHREADS = 512;
 
 struct Stage2 { uint4 v[2]; };
 
-// 128 rows x 32 halves of one operand part = 512 cells of 16 B; thread `tid` moves cells tid, tid+256
+// 256 rows x 32 halves of one operand part = 1024 cells of 16 B; thread `tid` moves cells tid, tid+512
 __device__ __forceinline__ Stage2 load_part(int tid, int kt, const half_t *base, int ldp, int row0, int rlast)
 {
     Stage2 s;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        const int c = tid + GTHREADS * i, row = c >> 2, kc = c & 3;
         int rg = row0 + row;
         rg = rg > rlast ? rlast : rg;
         s.v[i] = *reinterpret_cast<const uint4 *>(base + (size_t)rg * ldp + kt * GBK + kc * 8);
@@ -140,22 +145,24 @@ __device__ __forceinline__ void write_part(int tid, uint4 *part, const Stage2 &s
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        const int c = tid + GTHREADS * i, row = c >> 2, kc = c & 3;
         part[row * 4 + (kc ^ ((row >> 2) & 3))] = s.v[i];
     }
 }
 
 template <int EPI, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(xb::GemmParams p)
+__global__ __launch_bounds__(GTHREADS, 2) void gemm_kernel(xb::GemmParams p)
 {
     constexpr int NPART = NSPLIT == 3 ? 4 : 2;               // Ahi,(Alo),Bhi,(Blo)
-    __shared__ uint4 lds[2][NPART][GT * 4];
+    constexpr int PA_LO = 1, PB_HI = NSPLIT == 3 ? 2 : 1, PB_LO = 3;
+    constexpr int WM = 4, WN = 2;                             // 32x32 tiles per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4(*lds)[NPART][GBM * 4] = reinterpret_cast<uint4(*)[NPART][GBM * 4]>(smem_raw);   // [2][NPART][1024]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const int nk = p.K / GBK;
 
-    // staging registers: one 16-byte cell pair per operand part (A hi, A lo, B hi, B lo)
     Stage2 sAh, sAl, sBh, sBl;
     const int Mlast = p.M - 1, Nlast = p.Nn - 1;
 #define XB_LOAD_REGS(kt)                                                              \
@@ -170,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(xb::GemmParams p)
 #define XB_WRITE_LDS(st)                                                              \
     do {                                                                              \
         write_part(tid, lds[(st)][0], sAh);                                           \
-        write_part(tid, lds[(st)][NSPLIT == 3 ? 2 : 1], sBh);                         \
+        write_part(tid, lds[(st)][PB_HI], sBh);                                       \
         if (NSPLIT == 3) {                                                            \
-            write_part(tid, lds[(st)][1], sAl);                                       \
-            write_part(tid, lds[(st)][3], sBl);                                       \
+            write_part(tid, lds[(st)][PA_LO], sAl);                                   \
+            write_part(tid, lds[(st)][PB_LO], sBl);                                   \
         }                                                                             \
     } while (0)
     auto frag = [&](int st, int q, int rb, int s) -> half8 {
@@ -182,62 +189,65 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(xb::GemmParams p)
         return __builtin_bit_cast(half8, v);
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // pipeline: LDS holds tile kt, the staging registers hold tile kt+1 (written to the other stage at the START
+    // of iteration kt, so the ds_writes overlap other waves' MFMAs), global loads of tile kt+2 are in flight.
     XB_LOAD_REGS(0);
     XB_WRITE_LDS(0);
+    if (nk > 1) XB_LOAD_REGS(1);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int st = kt & 1;
-        if (kt + 1 < nk) XB_LOAD_REGS(kt + 1);
+        if (kt + 1 < nk) XB_WRITE_LDS(st ^ 1);
+        if (kt + 2 < nk) XB_LOAD_REGS(kt + 2);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            half8 ah[2], al[2], bh[2], bl[2];
+            half8 bh[WN], bl[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = frag(st, 0, 2 * wm + i, s);
-                bh[i] = frag(st, NSPLIT == 3 ? 2 : 1, 2 * wn + i, s);
-                if (NSPLIT == 3) {
-                    al[i] = frag(st, 1, 2 * wm + i, s);
-                    bl[i] = frag(st, 3, 2 * wn + i, s);
-                }
+            for (int j = 0; j < WN; ++j) {
+                bh[j] = frag(st, PB_HI, WN * wn + j, s);
+                if (NSPLIT == 3) bl[j] = frag(st, PB_LO, WN * wn + j, s);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WM; ++i) {
+                const half8 ah = frag(st, 0, WM * wm + i, s);
+                half8 al;
+                if (NSPLIT == 3) al = frag(st, PA_LO, WM * wm + i, s);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < WN; ++j) {
                     if (NSPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
+            }
         }
-        if (kt + 1 < nk) XB_WRITE_LDS(st ^ 1);
         __syncthreads();
     }
-
-    // epilogue: lane holds column n (lane & 31) and 16 rows per tile
 #undef XB_LOAD_REGS
 #undef XB_WRITE_LDS
+
+    // epilogue: lane holds column n (lane & 31) and 16 rows per tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wn * (WN * 32) + j * 32 + (lane & 31);
             if (n >= p.Nn) continue;
             const float bias = p.bias ? p.bias[n] : 0.0f;
             int ocol = n;
             if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (WM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
                 const float v = acc[i][j][r] + bias;
                 if (EPI == xb::EPI_BIAS_F32) {
@@ -278,6 +288,7 @@ constexpr int LG_BN = 64;        // chunks per group (2 MFMA column tiles)
 constexpr int LG_UNITS = 32;     // hidden units per member workgroup
 constexpr unsigned long long LG_SPIN_CYCLES = 4000000000ull;   // ~2 s at 2 GHz
 constexpr int CPOL_SC1 = 16;     // gfx940+ cache-policy immediate: sc0 = 1, nt = 2, sc1 = 16
+constexpr int ST_LD = 68;        // dword stride of one unit-pair row of the h staging (64 chunks + 4: 2-way reads)
 
 __device__ __forceinline__ void dma16_sc1(const void *g, void *lds_wave_base)
 {
@@ -321,8 +332,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
-    half_t *sT = reinterpret_cast<half_t *>(smem_raw + 2 * NPARTS * PIECE_BYTES); // [NPARTS][64][32]
-    float *sC = reinterpret_cast<float *>(sT + NPARTS * LG_BN * LG_UNITS);          // [32 units][64 chunks] cell state
+    // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
+    unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
+    float *sC = reinterpret_cast<float *>(sT + NPARTS * 16 * ST_LD);                // [32 units][64 chunks] cell state
     int *sFlag = reinterpret_cast<int *>(sC + LG_UNITS * LG_BN);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -487,9 +499,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             }
         }
 
-        // gates -> cell -> hidden; stage h (split fp16) in LDS as [chunk][unit]
+        // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
+        // with the other half-wave's units so that each lane packs two ADJACENT units into one dword, written to
+        // the [pair][chunk] staging (consecutive lanes -> consecutive dwords: conflict-free).
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            unsigned phi[4], plo[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
@@ -502,16 +517,37 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 const float hv = og * fast_tanh(cn);
                 half_t hi, lo;
                 split_f16(hv, hi, lo);
-                const int o = (nt * 32 + (lane & 31)) * LG_UNITS + wid * 8 + 2 * rg + hsel;
-                sT[o] = hi;
-                if (NSPLIT == 3) sT[LG_BN * LG_UNITS + o] = lo;
+                phi[rg] = (unsigned)__builtin_bit_cast(unsigned short, hi);
+                plo[rg] = (unsigned)__builtin_bit_cast(unsigned short, lo);
             }
+            // lanes < 32 hold even units v[rg] = unit 2rg, lanes >= 32 the odd ones v[rg] = unit 2rg+1.
+            // v_permlane32_swap(vdst, src) exchanges vdst's upper half-wave with src's lower half-wave, so
+            //   swap(v[0], v[2]) -> {r[0], r[1]} = low lanes {unit 0, unit 1}, high lanes {unit 4, unit 5}
+            //   swap(v[1], v[3]) -> low lanes {unit 2, unit 3}, high lanes {unit 6, unit 7}
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+                unsigned *v = part == 0 ? phi : plo;
+                auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+                const unsigned e0 = r0[0], o0 = r0[1], e1 = r1[0], o1 = r1[1];
+                const int pr = wid * 4 + hsel * 2;                  // first unit pair of this lane
+                unsigned *dst = sT + part * 16 * ST_LD + nt * 32 + (lane & 31);
+                dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
+                dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
+            }
+        }
         __syncthreads();
-        // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part
+        // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part (cell = 4 unit pairs of one chunk)
         const int orow = tid >> 2, occ = tid & 3;
-        const uint4 vhi = *reinterpret_cast<const uint4 *>(sT + orow * LG_UNITS + occ * 8);
-        uint4 vlo = make_uint4(0, 0, 0, 0);
-        if (NSPLIT == 3) vlo = *reinterpret_cast<const uint4 *>(sT + LG_BN * LG_UNITS + orow * LG_UNITS + occ * 8);
+        uint4 vhi, vlo = make_uint4(0, 0, 0, 0);
+        {
+            const unsigned *src = sT + (occ * 4) * ST_LD + orow;
+            vhi = make_uint4(src[0], src[ST_LD], src[2 * ST_LD], src[3 * ST_LD]);
+            if (NSPLIT == 3) {
+                const unsigned *sl = src + 16 * ST_LD;
+                vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
+            }
+        }
         const bool more = s + 1 < p.s_end || !p.persistent;
         if (more && s + 1 < T) {
             // publish h_t for the group (rows beyond the slab are scratch rows of the exchange buffer)
@@ -558,7 +594,7 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const int g8 = (ngroups + 7) & ~7;
     const int members = F / LG_UNITS;
-    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * LG_BN * LG_UNITS * 2 +
+    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
                        sizeof(float) * LG_UNITS * LG_BN + 16;
     dim3 grid(g8 * members), block(256);
     if (p.nsplit == 3)
@@ -571,11 +607,17 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 template <int EPI>
 hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
 {
-    dim3 grid((p.Nn + GT - 1) / GT, (p.M + GT - 1) / GT), block(256);
-    if (p.nsplit == 3)
-        hipLaunchKernelGGL((gemm_kernel<EPI, 3>), grid, block, 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<EPI, 1>), grid, block, 0, stream, p);
+    dim3 grid((p.Nn + GBN - 1) / GBN, (p.M + GBM - 1) / GBM), block(GTHREADS);
+    const size_t lds = (size_t)2 * (p.nsplit == 3 ? 4 : 2) * GBM * 4 * sizeof(uint4);
+    if (p.nsplit == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_kernel<EPI, 3>), grid, block, lds, stream, p);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_kernel<EPI, 1>), grid, block, lds, stream, p);
+    }
     return hipGetLastError();
 }
 
