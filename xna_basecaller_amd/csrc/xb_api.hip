@@ -57,7 +57,7 @@ struct xb_ctx {
     half_t *x_hi[2] = {}, *x_lo[2] = {};
     float *gin = nullptr, *c_state = nullptr, *scores = nullptr;
     half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
-    float *alpha = nullptr, *beta = nullptr, *bmax = nullptr;
+    float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
     int32_t *seq_len = nullptr;
     unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
@@ -295,6 +295,7 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
     p.cin = has_blank ? ctx->S * (c.n_base + 1) : ctx->S * c.n_base;
     p.ld = ld; p.has_blank = has_blank; p.blank = c.blank_score;
     p.alpha = ctx->alpha; p.beta = ctx->beta; p.bmax = ctx->bmax; p.logz = nullptr;
+    p.qbuf = ctx->qbuf; p.ldq = (ctx->S * (c.n_base + 1) + 3) & ~3;
     p.labels = d_labels; p.seq = d_seq; p.seq_len = d_len;
     memset(p.alphabet, 0, sizeof p.alphabet);
     if (alphabet) {
@@ -303,6 +304,9 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
     } else if (d_seq) {
         return fail(ctx, XB_ERR_INVALID, "alphabet is required when seq is requested");
     }
+#ifdef XB_LSTM_STAMPS
+    if (const char *e = getenv("XB_DECODE_STOP")) p.debug_stop = atoi(e);
+#endif
     StageScope sc(ctx, XB_STAGE_DECODE, 1);
     hipError_t e = xb::launch_crf_decode(p, ctx->stream);
     if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? XB_ERR_INVALID : XB_ERR_HIP, "crf decode launch failed: %s", hipGetErrorString(e));
@@ -395,6 +399,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->qbuf, T * N * ((Cb + 3) & ~(size_t)3));
     rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);

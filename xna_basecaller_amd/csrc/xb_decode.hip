@@ -11,9 +11,12 @@
 // Scores stream from HBM through a register ring (D steps ahead) in 4/8/16-byte coalesced
 // loads, are staged in LDS and consumed by state.  Three sweeps over the scores:
 //   1. Log forward           (write alpha)
-//   2. Log backward fused with Max backward (read alpha; write beta, bmax)
-//   3. Max forward with recomputed log-posterior + per-step arg-max of the max-marginals
-//      (read alpha, beta, bmax), then pack.
+//   2. Log backward fused with Max backward (read alpha; write beta, bmax) -- also writes the
+//      log-posteriors Q = log(P + 1e-8) of every edge, (T, N, S*E) fp32, staged by destination
+//      edge in LDS and stored as coalesced rows one step late
+//   3. Max forward over Q + per-step arg-max of the max-marginals (read Q, bmax), then pack.
+// (Storing Q trades C*4 extra bytes per step for not recomputing 2*E transcendentals per state
+//  in sweep 3, which then is as light as sweep 1; the values are the same floats either way.)
 //
 // Floating-point contract (shared by specification with oracle/xna_oracle.c, written
 // independently): IEEE binary32, no contraction (this file is built with -ffp-contract=off),
@@ -138,6 +141,32 @@ struct ScoreRing {
 
 constexpr int DEPTH = 4;   // time steps of scores in flight per workgroup
 
+// wave64 arg-max of (value, flat index), ties to the lowest index, on DPP row shifts / row broadcasts
+// (no LDS round trips).  The result is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmax_dpp_step(float &v, int &c)
+{
+    // lanes without a source keep `old` = the identity (-inf, INT_MAX)
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        (int)0xff800000, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+    const int oc = __builtin_amdgcn_update_dpp(0x7fffffff, c, CTRL, ROW_MASK, 0xf, false);
+    if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; }
+}
+// value held by the other lane of an adjacent lane pair (quad_perm [1,0,3,2])
+__device__ __forceinline__ float dpp_swap(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void wave_argmax(float &v, int &c)
+{
+    argmax_dpp_step<0x111, 0xf>(v, c);   // row_shr:1
+    argmax_dpp_step<0x112, 0xf>(v, c);   // row_shr:2
+    argmax_dpp_step<0x114, 0xf>(v, c);   // row_shr:4
+    argmax_dpp_step<0x118, 0xf>(v, c);   // row_shr:8   -> lane 15 of every row holds the row result
+    argmax_dpp_step<0x142, 0xa>(v, c);   // row_bcast:15 into rows 1 and 3
+    argmax_dpp_step<0x143, 0xc>(v, c);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave result
+}
+
 // M[j][k] from the staged row: with the blank column present it is lds[j*E+k]; otherwise column 0
 // is the constant blank and column k>=1 is lds[j*NB + k-1].
 template <int NB, bool HB>
@@ -148,20 +177,23 @@ __device__ __forceinline__ float score_at(const float *lds, int j, int k, float 
     return k == 0 ? blank : lds[j * NB + k - 1];
 }
 
-template <int NB, int BS, int VW, bool HB>
+// LPS = lanes per state in sweep 2 (1 or 2); the block has BS >= LPS*S threads, sweeps 1 and 3 use the first S.
+template <int NB, int BS, int VW, bool HB, int LPS>
 __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 {
     constexpr int E = NB + 1;
-    constexpr int NR = (E + VW - 1) / VW;           // BS*NR*VW >= S*E >= cin
+    constexpr int NR = (E + LPS * VW - 1) / (LPS * VW);   // BS*NR*VW >= LPS*S*NR*VW >= S*E >= cin
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin;
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
     const bool act = tid < S;
-    constexpr int cpad = BS * NR * VW;           // staging row incl. parking space for out-of-range groups
+    constexpr int cpad = BS * 8;                 // staging row (>= BS*NR*VW and >= BS*NRQ*4) incl. parking space
+    constexpr int NRQ = (E + 4 * LPS - 1) / (4 * LPS);   // 16-byte groups per thread of a Q row (S*E floats)
 
     float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]
-    float *sA = sM + 2 * cpad;                                    // [2][S]  alpha / beta
+    float *sQ = sM + 2 * cpad;                                    // [2][cpad] log-posterior rows (sweep 2)
+    float *sA = sQ + 2 * cpad;                                    // [2][S]  alpha / beta
     float *sX = sA + 2 * S;                                       // [2][S]  max-plus alpha / beta
     float *sG = sX + 2 * S;                                       // [2][S]  gathered alpha row (sweep 3)
     float *sRv = sG + 2 * S;                                      // [2][BS/64] arg-max partials
@@ -245,10 +277,25 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
     const float logZ = sBc[1];
+#ifdef XB_LSTM_STAMPS
+    if (p.debug_stop == 1) return;   // diagnostic build only: time sweep 1 alone
+#endif
 
     // -------------------------------------------- sweep 2: Log backward + Max backward (fused)
+    float *qrow = p.qbuf + (size_t)n * p.ldq;
+    const size_t qstride = (size_t)N * p.ldq;
     {
         float aring[DEPTH];
+        // LPS == 1: thread = source state.  LPS == 2: an adjacent lane pair shares a state, lane `ph` owns the
+        // out-edges e = ph*E0 .. (stay first, then new base b = e-1); exps/logs run in both lanes, the ORDERED
+        // logsumexp sum is finished in lane 0 with the partner's terms fetched by DPP in edge order.
+        constexpr int E0 = LPS == 2 ? (E + 1) / 2 : E;
+        const int i = LPS == 2 ? tid >> 1 : tid;
+        const int ph = LPS == 2 ? tid & 1 : 0;
+        const bool act2 = i < S;
+        const int ic = act2 ? i : S - 1;
+        const int kk = ic / hi + 1;
+        const int jb = (ic % hi) * NB;
         if (act) {
             sA[(T & 1) * S + tid] = 0.0f;
             sX[(T & 1) * S + tid] = 0.0f;
@@ -259,17 +306,26 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         for (int d = 0; d < DEPTH; ++d) {
             const int t = T - 1 - d >= 0 ? T - 1 - d : 0;
             ring[d].load(sc + (size_t)t * tstride, cin, tid);
-            ld_asm(aring[d], alpha + (size_t)t * sstride + stid);
+            ld_asm(aring[d], alpha + (size_t)t * sstride + ic);
         }
-        const int i = tid;
-        const int kk = i / hi + 1;
-        const int jb = (i % hi) * NB;
+        // the Q row of step t is complete once every thread has passed the barrier of step t-1:
+        // it is stored (coalesced 16-byte groups) during iteration t-1
+        auto store_qrow = [&](int t) {
+            const float *src = sQ + (t & 1) * cpad;
+            float *dst = qrow + (size_t)t * qstride;
+#pragma unroll
+            for (int r = 0; r < NRQ; ++r) {
+                const int g = (tid + BS * r) * 4;
+                if (g < p.ldq) *reinterpret_cast<f32x4 *>(dst + g) = *reinterpret_cast<const f32x4 *>(src + g);
+            }
+        };
         for (int s0 = 0; s0 < T; s0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int t = T - 1 - (s0 + d);
                 if (t >= 0) {
                     float *m = sM + (t & 1) * cpad;
+                    float *qs = sQ + (t & 1) * cpad;
                     wait_vm<(DEPTH - 1) * (NR + 1)>();
                     ring[d].store(m, tid);
                     pin(aring[d]);
@@ -277,63 +333,79 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                     {
                         const int tn = t - DEPTH >= 0 ? t - DEPTH : 0;
                         ring[d].load(sc + (size_t)tn * tstride, cin, tid);
-                        ld_asm(aring[d], alpha + (size_t)tn * sstride + stid);
+                        ld_asm(aring[d], alpha + (size_t)tn * sstride + ic);
                     }
                     lds_barrier();
-                    if (act) {
+                    if (t + 1 < T) store_qrow(t + 1);
+                    if (act2) {
                         const float *b1 = sA + ((t + 1) & 1) * S;
                         const float *m1 = sX + ((t + 1) & 1) * S;
-                        float y[E], q[E], mb[E];
-                        {
-                            const float mv = score_at<NB, HB>(m, i, 0, blank);
-                            const float bj = b1[i];
-                            y[0] = mv + bj;
-                            const float xx = ((a0 + mv) + bj) - logZ;
-                            q[0] = xb_logf(xb_expf(xx) + 1e-8f);
-                            mb[0] = m1[i];
-                        }
+                        float y[E0], q[E0], mb[E0];
+                        bool val[E0];
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const int j = jb + b;
-                            const float mv = score_at<NB, HB>(m, j, kk, blank);
+                        for (int r = 0; r < E0; ++r) {
+                            const int e = ph * E0 + r;               // edge: 0 = stay, e >= 1 = new base e-1
+                            val[r] = e < E;
+                            const int ee = val[r] ? e : 0;
+                            const int j = ee == 0 ? ic : jb + ee - 1;
+                            const int k = ee == 0 ? 0 : kk;
+                            const float mv = score_at<NB, HB>(m, j, k, blank);
                             const float bj = b1[j];
-                            y[b + 1] = mv + bj;
+                            y[r] = mv + bj;
                             const float xx = ((a0 + mv) + bj) - logZ;
-                            q[b + 1] = xb_logf(xb_expf(xx) + 1e-8f);
-                            mb[b + 1] = m1[j];
+                            q[r] = xb_logf(xb_expf(xx) + 1e-8f);
+                            mb[r] = m1[j];
+                            if (val[r]) qs[j * E + k] = q[r];
                         }
-                        float mx = y[0];
-#pragma unroll
-                        for (int e = 1; e < E; ++e) mx = maxf(mx, y[e]);
-                        float s = xb_expf(y[0] - mx);
-#pragma unroll
-                        for (int e = 1; e < E; ++e) s += xb_expf(y[e] - mx);
-                        const float bv = mx + xb_logf(s);
+                        float mx = y[0];                             // r = 0 is always a valid edge
                         float mm = q[0] + mb[0];
 #pragma unroll
-                        for (int e = 1; e < E; ++e) mm = maxf(mm, q[e] + mb[e]);
-                        sA[(t & 1) * S + i] = bv;
-                        sX[(t & 1) * S + i] = mm;
-                        beta[(size_t)t * sstride + i] = bv;
-                        bmax[(size_t)t * sstride + i] = mm;
+                        for (int r = 1; r < E0; ++r)
+                            if (val[r]) { mx = maxf(mx, y[r]); mm = maxf(mm, q[r] + mb[r]); }
+                        if (LPS == 2) {
+                            mx = maxf(mx, dpp_swap(mx));             // max is exact: any order
+                            mm = maxf(mm, dpp_swap(mm));
+                        }
+                        float ex[E0];
+#pragma unroll
+                        for (int r = 0; r < E0; ++r) ex[r] = xb_expf(y[r] - mx);
+                        float s = ex[0];
+#pragma unroll
+                        for (int r = 1; r < E0; ++r) s += ex[r];     // lane 0: edges 0..E0-1 in order
+                        if (LPS == 2) {
+#pragma unroll
+                            for (int r = 0; r < E - E0; ++r) s += dpp_swap(ex[r]);   // then the partner's, in order
+                        }
+                        const float bv = mx + xb_logf(s);
+                        if (ph == 0) {
+                            sA[(t & 1) * S + ic] = bv;
+                            sX[(t & 1) * S + ic] = mm;
+                            beta[(size_t)t * sstride + ic] = bv;
+                            bmax[(size_t)t * sstride + ic] = mm;
+                        }
                     }
                 }
             }
         }
+        lds_barrier();
+        store_qrow(0);
         wait_vm<0>();
         __syncthreads();
     }
 
-    // --------------------------- sweep 3: Max forward + per-step arg-max of the max-marginals
+#ifdef XB_LSTM_STAMPS
+    if (p.debug_stop == 2) return;   // diagnostic build only: sweeps 1+2
+#endif
+    // --------------------------- sweep 3: Max forward over Q + per-step arg-max of the max-marginals
     {
-        float aring[DEPTH], bring[DEPTH], mring[DEPTH];
+        ScoreRing<4, NRQ, BS> qring[DEPTH];
+        float mring[DEPTH];
+        const int ldq = p.ldq;
         if (act) sX[tid] = 0.0f;
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int t = d < T ? d : T - 1;
-            ring[d].load(sc + (size_t)t * tstride, cin, tid);
-            ld_asm(aring[d], alpha + (size_t)t * sstride + stid);
-            ld_asm(bring[d], beta + (size_t)(t + 1) * sstride + stid);
+            qring[d].load(qrow + (size_t)t * qstride, ldq, tid);
             ld_asm(mring[d], bmax + (size_t)(t + 1) * sstride + stid);
         }
         const int j = tid;
@@ -345,16 +417,13 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 const int t = t0 + d;
                 if (t < T) {
                     float *m = sM + (t & 1) * cpad;
-                    wait_vm<(DEPTH - 1) * (NR + 3)>();
-                    ring[d].store(m, tid);
-                    pin(aring[d]); pin(bring[d]); pin(mring[d]);
-                    if (act) sG[(t & 1) * S + j] = aring[d];
-                    const float b1j = bring[d], m1j = mring[d];
+                    wait_vm<(DEPTH - 1) * (NRQ + 1)>();
+                    qring[d].store(m, tid);
+                    pin(mring[d]);
+                    const float m1j = mring[d];
                     {
                         const int tn = t + DEPTH < T ? t + DEPTH : T - 1;
-                        ring[d].load(sc + (size_t)tn * tstride, cin, tid);
-                        ld_asm(aring[d], alpha + (size_t)tn * sstride + stid);
-                        ld_asm(bring[d], beta + (size_t)(tn + 1) * sstride + stid);
+                        qring[d].load(qrow + (size_t)tn * qstride, ldq, tid);
                         ld_asm(mring[d], bmax + (size_t)(tn + 1) * sstride + stid);
                     }
                     lds_barrier();
@@ -371,12 +440,10 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                     float best = -__builtin_inff();
                     int bestc = 0x7fffffff;
                     if (act) {
-                        const float *a0 = sG + (t & 1) * S;
                         const float *am = sX + (t & 1) * S;
                         float mm;
                         {
-                            const float xx = ((a0[j] + score_at<NB, HB>(m, j, 0, blank)) + b1j) - logZ;
-                            const float Q = xb_logf(xb_expf(xx) + 1e-8f);
+                            const float Q = m[j * E];
                             const float av = am[j];
                             mm = Q + av;
                             best = (av + Q) + m1j;
@@ -385,8 +452,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 #pragma unroll
                         for (int k = 1; k < E; ++k) {
                             const int src = (k - 1) * hi + jq;
-                            const float xx = ((a0[src] + score_at<NB, HB>(m, j, k, blank)) + b1j) - logZ;
-                            const float Q = xb_logf(xb_expf(xx) + 1e-8f);
+                            const float Q = m[j * E + k];
                             const float av = am[src];
                             mm = maxf(mm, Q + av);
                             const float scv = (av + Q) + m1j;
@@ -394,14 +460,8 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                         }
                         sX[((t + 1) & 1) * S + j] = mm;
                     }
-                    // wave arg-max, ties to the lowest flat index
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const float ov = __shfl_xor(best, off, 64);
-                        const int oi = __shfl_xor(bestc, off, 64);
-                        if (ov > best || (ov == best && oi < bestc)) { best = ov; bestc = oi; }
-                    }
-                    if (lane == 0) {
+                    wave_argmax(best, bestc);
+                    if (lane == 63) {
                         sRv[(t & 1) * (BS / 64) + wave] = best;
                         sRi[(t & 1) * (BS / 64) + wave] = bestc;
                     }
@@ -452,17 +512,15 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     }
 }
 
-template <int NB, int BS>
+template <int NB, int BS, int LPS>
 hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    constexpr int E = NB + 1;
-    const int nr = (E + vw - 1) / vw;
-    const int cpad = BS * nr * vw;
-    size_t lds = sizeof(float) * (2 * (size_t)cpad + 6 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
+    const int cpad = BS * 8;
+    size_t lds = sizeof(float) * (4 * (size_t)cpad + 6 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
                  sizeof(float) * 4 + (size_t)p.T;
     lds = (lds + 15) & ~(size_t)15;
     dim3 grid(p.N), block(BS);
-#define XB_LAUNCH(VW, HB) hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB>), grid, block, lds, stream, p)
+#define XB_LAUNCH(VW, HB) hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB, LPS>), grid, block, lds, stream, p)
     if (p.has_blank) {
         if (vw == 4) XB_LAUNCH(4, true); else if (vw == 2) XB_LAUNCH(2, true); else XB_LAUNCH(1, true);
     } else {
@@ -472,13 +530,16 @@ hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
     return hipGetLastError();
 }
 
+// two lanes per state in sweep 2 while the doubled block stays within 256 threads (measured on MI355X at
+// N = 512: nb = 5 gains 17 %, a 512-thread block for nb = 6 loses 10 % to barrier / arg-max overheads)
 template <int NB>
 hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    if (p.S <= 64) return launch_nb_bs<NB, 64>(p, vw, stream);
-    if (p.S <= 128) return launch_nb_bs<NB, 128>(p, vw, stream);
-    if (p.S <= 256) return launch_nb_bs<NB, 256>(p, vw, stream);
-    return launch_nb_bs<NB, 1024>(p, vw, stream);
+    if (2 * p.S <= 64) return launch_nb_bs<NB, 64, 2>(p, vw, stream);
+    if (2 * p.S <= 128) return launch_nb_bs<NB, 128, 2>(p, vw, stream);
+    if (2 * p.S <= 256) return launch_nb_bs<NB, 256, 2>(p, vw, stream);
+    if (p.S <= 256) return launch_nb_bs<NB, 256, 1>(p, vw, stream);
+    return launch_nb_bs<NB, 1024, 1>(p, vw, stream);
 }
 
 }  // namespace
@@ -493,7 +554,7 @@ hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
     if (p.S < 1 || p.S > 1024 || p.T < 1 || p.N < 1) return hipErrorInvalidValue;
     const int E = p.nb + 1;
     if (p.cin != (p.has_blank ? p.S * E : p.S * p.nb) || p.ld < p.cin) return hipErrorInvalidValue;
-    const int bs = p.S <= 64 ? 64 : p.S <= 128 ? 128 : p.S <= 256 ? 256 : 1024;
+    if (!p.qbuf || p.ldq % 4 != 0 || p.ldq < p.S * E || reinterpret_cast<uintptr_t>(p.qbuf) % 16 != 0) return hipErrorInvalidValue;
     int vw = 1;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p.scores);
     // vector loads may run into the row's padding columns (ld >= cin rounded up), never past the row

@@ -14,11 +14,14 @@ struct DecodeParams {
     int cin, ld, has_blank;
     float blank;
     float *alpha, *beta, *bmax;   // (T+1, N, S) fp32 stashes
+    float *qbuf;                  // (T, N, ldq) fp32 log-posteriors written by sweep 2, read by sweep 3
+    int ldq;                      // >= S*(nb+1), multiple of 4
     float *logz;                  // (N) or nullptr
     int8_t *labels;               // (N, T) or nullptr
     int8_t *seq;                  // (N, T) or nullptr
     int32_t *seq_len;             // (N) or nullptr
     char alphabet[8];
+    int debug_stop;               // diagnostic builds only (XB_LSTM_STAMPS): return after sweep 1 / 2
 };
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream);
 
