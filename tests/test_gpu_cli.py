@@ -1,0 +1,96 @@
+"""GPU: `bonito basecaller`-compatible CLI end to end (BASELINE configs[0] shape:
+16 reads, chunksize 4000, small batch): model directory (config.toml + weights_N.tar with a dropout-interleaved
+training state dict) + signal bundle -> FASTQ on stdout + <stem>_summary.tsv, compared with the all-oracle pipeline."""
+import os
+import subprocess
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, encoder_shapes, make_config, seeded_state_dict
+from xna_basecaller_amd import reads as xreads
+from xna_basecaller_amd import toml_lite, util
+
+pytestmark = pytest.mark.gpu
+
+# training-time module indices of the dropout-interleaved encoder (crf/model.py:183-201) -> inference indices
+TRAIN_INDEX = {0: 0, 1: 2, 2: 4, 4: 7, 5: 9, 6: 11, 7: 13, 8: 15, 9: 16}
+
+
+def _make_model_dir(path, features, labels, seed):
+    import torch
+    cfg = make_config(features, labels)
+    cfg["model"]["package"] = "bonito.crf"
+    cfg["basecaller"] = {"batchsize": 5, "chunksize": 4000, "overlap": 500}
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.toml"), "w") as fh:
+        fh.write(toml_lite.dumps(cfg))
+    keys, shapes = encoder_shapes(features, len(labels) - 1)
+    sd = seeded_state_dict(keys, shapes, seed)
+    train = OrderedDict()
+    for k, v in sd.items():
+        idx = int(k.split(".")[1])
+        train["module." + k.replace("encoder.%d." % idx, "encoder.%d." % TRAIN_INDEX[idx])] = torch.from_numpy(v)
+    torch.save(train, os.path.join(path, "weights_3.tar"))
+    torch.save({k: torch.zeros_like(v) for k, v in train.items()}, os.path.join(path, "weights_1.tar"))  # older checkpoint
+    return cfg, sd
+
+
+def _make_reads(path, n):
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(n):
+        length = int(rng.integers(3000, 16000))
+        base = rng.normal(90.0, 12.0, length)
+        lead = int(rng.integers(300, 900))
+        base[:lead] = rng.normal(140.0, 3.0, lead)
+        raw = np.round(base * 8.0).astype(np.int16)
+        recs.append((raw, dict(read_id="read-%02d" % i, range=1443.03, digitisation=8192.0, offset=10,
+                               sampling_rate=4000.0, run_id="runX", channel_number=str(100 + i), start_mux=1 + i % 4,
+                               read_number=i, start_time=4000 * i, duration=length,
+                               exp_start_time="2021-06-01T10:00:00Z")))
+    os.makedirs(path, exist_ok=True)
+    xreads.write_bundle(os.path.join(path, "batch0.xsig.npz"), recs[: n // 2])
+    xreads.write_bundle(os.path.join(path, "batch1.xsig.npz"), recs[n // 2:])
+
+
+def test_cli_basecaller_end_to_end(tmp_path):
+    labels = list("NACGTXY")
+    model_dir = str(tmp_path / "xna_test@v1")
+    reads_dir = str(tmp_path / "reads")
+    cfg, sd = _make_model_dir(model_dir, 64, labels, seed=21)
+    _make_reads(reads_dir, 16)
+    ids = tmp_path / "ids.tsv"
+    ids.write_text("".join("read-%02d\n" % i for i in range(16) if i != 5))
+    out = tmp_path / "calls.fastq"
+    with open(out, "w") as fh:
+        r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir,
+                            "--read-ids", str(ids), "--batch", "7", "-v"], cwd=ROOT, stdout=fh, stderr=subprocess.PIPE,
+                           timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert "> outputting unaligned fastq" in err and "> samples per second" in err and "> completed reads: 15" in err
+    recs = out.read_text().strip().split("\n")
+    assert len(recs) == 4 * 15
+    summary = (tmp_path / "calls_summary.tsv").read_text().strip().split("\n")
+    assert len(summary) == 16 and summary[0].split("\t")[1] == "read_id"
+
+    # oracle pipeline on the same reads (file order, read-id filter applied)
+    expect = [rd for rd in xreads.get_reads(reads_dir, read_ids=util.column_to_set(str(ids)))]
+    assert [rec[1:].split(" ")[0] for rec in recs[0::4]] == [rd.read_id for rd in expect]
+    total = mism = 0
+    for rd, hdr, seq, qs in zip(expect, recs[0::4], recs[1::4], recs[3::4]):
+        ch = util.chunk(np.asarray(rd.signal, np.float32), 4000, 500)
+        lab = oracle.decode(oracle.encode(ch, sd, 64, 6, 3), 6, 3)["labels"]
+        packed, _, _ = oracle.pack(lab, "".join(labels))
+        st = util.stitch(packed, 4000, 500, len(rd.signal), 5)
+        ref = st[st != 0].astype(np.uint8).tobytes().decode()
+        assert hdr.startswith("@%s RG:Z:runX_%s\tqs:i:40\tmx:i:" % (rd.read_id, model_dir))
+        assert qs == "O" * len(seq)
+        total += max(len(ref), 1)
+        if seq != ref:
+            mism += sum(a != b for a, b in zip(seq, ref)) + abs(len(seq) - len(ref))
+    assert mism <= total // 500, (mism, total)       # encoder differences of ~1e-5 may flip a near-tie

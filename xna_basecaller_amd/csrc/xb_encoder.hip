@@ -305,12 +305,14 @@ __device__ __forceinline__ void store16_sc1(void *g, uint4 v)
 }
 
 #ifdef XB_LSTM_STAMPS
-// diagnostic build only: per-phase cycle sums of workgroup 0 (never compiled into the product)
+// diagnostic build only: per-phase cycle sums of workgroup 0 (never compiled into the product).  The sums are kept
+// in LDS (no vector-memory traffic, so the stamps neither drain vmcnt nor absorb store latencies) and copied out
+// once at the end of the kernel.
 __device__ unsigned long long g_lstm_stamps[8];
 #define XB_STAMP(i)                                                                         \
     do {                                                                                    \
         const unsigned long long now_ = __builtin_readcyclecounter();                       \
-        if (blockIdx.x == 0 && tid == 0) g_lstm_stamps[(i)] += now_ - stamp_prev;            \
+        if (tid == 0) sStamp[(i)] += now_ - stamp_prev;                                      \
         stamp_prev = now_;                                                                  \
     } while (0)
 #else
@@ -383,6 +385,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
 
 #ifdef XB_LSTM_STAMPS
+    unsigned long long *sStamp = reinterpret_cast<unsigned long long *>(sFlag + 4);
+    if (tid == 0) for (int i = 0; i < 8; ++i) sStamp[i] = 0;
     unsigned long long stamp_prev = __builtin_readcyclecounter();
 #endif
     for (int s = p.s_begin; s < p.s_end; ++s) {
@@ -576,6 +580,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
     }
 
+#ifdef XB_LSTM_STAMPS
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_lstm_stamps[i] += sStamp[i];
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
         if (cbase + nt * 32 + (lane & 31) <= nlast)
@@ -595,7 +602,7 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const int g8 = (ngroups + 7) & ~7;
     const int members = F / LG_UNITS;
     const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-                       sizeof(float) * LG_UNITS * LG_BN + 16;
+                       sizeof(float) * LG_UNITS * LG_BN + 16 + 80;
     dim3 grid(g8 * members), block(256);
     if (p.nsplit == 3)
         hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
