@@ -19,7 +19,8 @@ def _ctx(nb, T, N, sl=3, features=32):
 def _check(ctx, sc, nb, alphabet, sl=3, blank=None):
     seq, lens, labels = ctx.decode(sc, alphabet, want_labels=True)
     ref = oracle.decode(sc, nb, sl, blank_score=blank)["labels"]
-    assert np.array_equal(labels, ref), "label mismatches: %d of %d" % ((labels != ref).sum(), ref.size)
+    assert np.array_equal(labels, ref), "label mismatches: %d of %d at (chunk, t) %s" % (
+        (labels != ref).sum(), ref.size, np.argwhere(labels != ref)[:8].tolist())
     rseq, _, rlens = oracle.pack(ref, alphabet)
     assert np.array_equal(lens, rlens)
     assert np.array_equal(seq, rseq)
@@ -27,7 +28,13 @@ def _check(ctx, sc, nb, alphabet, sl=3, blank=None):
 
 @pytest.mark.parametrize("nb", [4, 5, 6])
 @pytest.mark.parametrize("with_blank", [True, False])
-def test_decode_bit_exact_random(nb, with_blank):
+@pytest.mark.parametrize("lps", [0, 1, 2, 4])
+def test_decode_bit_exact_random(nb, with_blank, lps, monkeypatch):
+    """lps = lanes per CRF state (0: the library's own choice); every variant must give the same bits."""
+    if lps:
+        if lps * nb ** 3 > 512:
+            pytest.skip("block would exceed 512 threads")
+        monkeypatch.setenv("XB_DECODE_LPS", str(lps))
     alphabet = "NACGTXY"[:nb + 1]
     T, N = 203, 5                                   # T not a multiple of the prefetch depth
     ctx = _ctx(nb, T, N)
@@ -77,6 +84,18 @@ def test_decode_full_length_chunks():
     ctx = _ctx(nb, T, N)
     sc = random_scores(T, N, nb, seed=99)
     _check(ctx, sc, nb, "NACGTXY")
+    ctx.close()
+
+
+@pytest.mark.parametrize("lps", [1, 2, 4])
+def test_decode_full_length_odd_stride(lps, monkeypatch):
+    """T = 2000 with the 5-base CRF and no blank column: row stride 625 floats (4-byte loads, deepest register
+    ring) -- the configuration that exposed reuse of a prefetch register behind an unconsumed load."""
+    monkeypatch.setenv("XB_DECODE_LPS", str(lps))
+    nb, T, N = 5, 2000, 4
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=123, with_blank=False)
+    _check(ctx, sc, nb, "NACGTX", blank=2.0)
     ctx.close()
 
 

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import random_scores
 from xna_basecaller_amd import _lib
-nb = int(os.environ.get("NB", 5)); N = 512; T = 2000
+nb = int(os.environ.get("NB", 5)); N = int(os.environ.get("N", 512)); T = int(os.environ.get("T", 2000))
 S = nb ** 3
 ctx = _lib.Context(0, nb, 3, 32, 19, 5, 5.0, 2.0, T * 5, N)
 g = torch.Generator(device="cuda"); g.manual_seed(1)

@@ -24,6 +24,7 @@
 // is max / ordered sum of exp / log, ties resolve to the lowest flat edge index.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "xb_internal.h"
 
@@ -101,45 +102,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<4> { using type = f32x4; };
 
-// ---- explicit prefetch control ------------------------------------------------------------------
-// hipcc's s_waitcnt insertion loses the in-order vmcnt arithmetic across the loop's control flow and waits
-// vmcnt(0/1) before every use of the ring, i.e. drains the whole prefetch each step.  Every global LOAD inside
-// the sweeps is therefore an inline-asm load the compiler does not track, and each ring slot is consumed behind
-// a hand-counted s_waitcnt vmcnt(N): N = (DEPTH-1) * (loads issued per step).  Stores issued in between also
-// count on vmcnt, in order, so ignoring them only makes the wait longer, never too short.
-__device__ __forceinline__ void ld_asm(float &d, const float *p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void ld_asm(f32x2 &d, const float *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p)); }
-__device__ __forceinline__ void ld_asm(f32x4 &d, const float *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// makes `x` opaque at this point: no use of x may be scheduled above a preceding wait_vm
-template <typename Tp> __device__ __forceinline__ void pin(Tp &x) { asm volatile("" : "+v"(x)); }
-
-// Score row of one (t, chunk): `cin` floats at the row pointer; all BS threads move groups of VW floats
-// (NR groups per thread).  Loads are unconditional: out-of-range groups re-read group 0 and are parked in the
-// padding of the LDS buffer (BS*NR*VW floats), so the memory part of the loop is branch-free.
+// ---- prefetch: register ring with PLAIN (compiler-visible) loads -------------------------------------------
+// Score / Q rows of the next RDEPTH steps are held in registers and staged through LDS once per step.  The loads
+// are ordinary loads, fully tracked by hipcc: nothing can be copied or reused while in flight.  (An inline-asm
+// load ring with hand-counted s_waitcnt was faster by ~8 % but NOT safe: hipcc may re-allocate or copy an asm
+// load's destination before the data arrives, and an issued-but-unconsumed load corrupts whatever reuses its
+// register; an LDS-DMA ring is safe but ~25 % slower, each DMA instruction stalls its wave for 60-185 cycles.)
+// The memory part of every sweep is branch-free -- loops run over T rounded up to RDEPTH with clamped
+// addresses, LDS staging is unconditional (padded buffers), only the arithmetic is guarded -- which is what
+// lets the compiler's own s_waitcnt insertion count the in-order loads (vmcnt(9..12)) instead of draining them.
 template <int VW, int NR, int BS>
-struct ScoreRing {
+struct RowRegs {
     using V = typename VecT<VW>::type;
     V r[NR];
-    __device__ __forceinline__ void load(const float *row, int cin, int tid)
+    __device__ __forceinline__ void load(const float *row, int lim, int tid)
     {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int g = (tid + BS * i) * VW;
-            ld_asm(r[i], row + (g < cin ? g : 0));
+            r[i] = *reinterpret_cast<const V *>(row + (g < lim ? g : 0));
         }
     }
-    __device__ __forceinline__ void store(float *lds, int tid)
+    __device__ __forceinline__ void store(float *lds, int tid) const
     {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            pin(r[i]);
-            *reinterpret_cast<V *>(lds + (tid + BS * i) * VW) = r[i];
-        }
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<V *>(lds + (tid + BS * i) * VW) = r[i];
     }
 };
+constexpr int RDEPTH = 4;  // register-ring depth (steps in flight)
 
-constexpr int DEPTH = 4;   // time steps of scores in flight per workgroup
 
 // wave64 arg-max of (value, flat index), ties to the lowest index, on DPP row shifts / row broadcasts
 // (no LDS round trips).  The result is valid in lane 63.
@@ -152,10 +143,38 @@ __device__ __forceinline__ void argmax_dpp_step(float &v, int &c)
     const int oc = __builtin_amdgcn_update_dpp(0x7fffffff, c, CTRL, ROW_MASK, 0xf, false);
     if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; }
 }
-// value held by the other lane of an adjacent lane pair (quad_perm [1,0,3,2])
-__device__ __forceinline__ float dpp_swap(float v)
+// ---- lane clusters: a state is served by LPS = 1, 2 or 4 adjacent lanes (inside one DPP quad) --------------
+template <int CTRL> __device__ __forceinline__ float quad_perm(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// max over the LPS lanes of a cluster (max is exact: any order)
+template <int LPS> __device__ __forceinline__ float cluster_max(float v)
+{
+    if (LPS >= 2) { const float o = quad_perm<0xB1>(v); v = o > v ? o : v; }    // quad_perm [1,0,3,2]
+    if (LPS >= 4) { const float o = quad_perm<0x4E>(v); v = o > v ? o : v; }    // quad_perm [2,3,0,1]
+    return v;
+}
+// value held by lane P of this lane's cluster
+template <int LPS, int P> __device__ __forceinline__ float cluster_get(float v)
+{
+    if (LPS == 1) return v;
+    if (LPS == 2) return quad_perm<(P) | (P << 2) | ((2 + P) << 4) | ((2 + P) << 6)>(v);   // pairs {0,1} {2,3}
+    return quad_perm<(P & 3) | ((P & 3) << 2) | ((P & 3) << 4) | ((P & 3) << 6)>(v);
+}
+// Ordered sum over the E terms of a cluster: lane p holds terms e = p*EPER + r in x[r]; every lane of the cluster
+// accumulates all terms in edge order e = 0..E-1 (the contract's summation order), fetching them by DPP.
+template <int LPS, int E, int EPER, int PP = 0, int R = 0>
+__device__ __forceinline__ void ordered_sum(const float (&x)[EPER], float &s)
+{
+    if constexpr (PP < LPS) {
+        if constexpr (PP * EPER + R < E) {
+            const float v = cluster_get<LPS, PP>(x[R]);
+            s = (PP == 0 && R == 0) ? v : s + v;
+        }
+        if constexpr (R + 1 < EPER) ordered_sum<LPS, E, EPER, PP, R + 1>(x, s);
+        else ordered_sum<LPS, E, EPER, PP + 1, 0>(x, s);
+    }
 }
 __device__ __forceinline__ void wave_argmax(float &v, int &c)
 {
@@ -177,28 +196,37 @@ __device__ __forceinline__ float score_at(const float *lds, int j, int k, float 
     return k == 0 ? blank : lds[j * NB + k - 1];
 }
 
-// LPS = lanes per state in sweep 2 (1 or 2); the block has BS >= LPS*S threads, sweeps 1 and 3 use the first S.
+// LPS = lanes per state (1, 2 or 4): the E edges of a state are split in blocks of EPER over LPS adjacent lanes;
+// the block has BS >= LPS*S threads.
 template <int NB, int BS, int VW, bool HB, int LPS>
 __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 {
     constexpr int E = NB + 1;
-    constexpr int NR = (E + LPS * VW - 1) / (LPS * VW);   // BS*NR*VW >= LPS*S*NR*VW >= S*E >= cin
+    constexpr int NW = BS / 64;
+    constexpr int EPER = (E + LPS - 1) / LPS;    // edges per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin;
-    const int tid = threadIdx.x;
+    const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin, ldq = p.ldq;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x;
-    const bool act = tid < S;
-    constexpr int cpad = BS * 8;                 // staging row (>= BS*NR*VW and >= BS*NRQ*4) incl. parking space
-    constexpr int NRQ = (E + 4 * LPS - 1) / (4 * LPS);   // 16-byte groups per thread of a Q row (S*E floats)
+    const int st = tid / LPS, ph = tid % LPS;    // state and position inside its lane cluster
+    const bool act = st < S;
+    const int stc = act ? st : S - 1;            // clamped state (always a valid column)
 
-    float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]
-    float *sQ = sM + 2 * cpad;                                    // [2][cpad] log-posterior rows (sweep 2)
+    constexpr int NR = (E + LPS * VW - 1) / (LPS * VW);   // BS*NR*VW >= LPS*S*NR*VW >= S*E >= cin
+    constexpr int NRQ = (E + 4 * LPS - 1) / (4 * LPS);   // 16-byte groups per thread of a Q row
+    constexpr int cpad = BS * 8;                          // staging row >= BS*NR*VW and >= BS*NRQ*4 (E <= 8)
+    const int lim_m = VW == 4 ? (cin + 3) & ~3 : cin;     // vector loads may touch the row's padding columns
+    const int Tpad = (T + RDEPTH - 1) / RDEPTH * RDEPTH;
+
+    float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]  staged score / Q row
+    float *sQ = sM + 2 * cpad;                                    // [2][cpad]  Q rows being assembled (sweep 2)
     float *sA = sQ + 2 * cpad;                                    // [2][S]  alpha / beta
     float *sX = sA + 2 * S;                                       // [2][S]  max-plus alpha / beta
-    float *sG = sX + 2 * S;                                       // [2][S]  gathered alpha row (sweep 3)
-    float *sRv = sG + 2 * S;                                      // [2][BS/64] arg-max partials
-    int *sRi = reinterpret_cast<int *>(sRv + 2 * (BS / 64));      // [2][BS/64]
-    float *sBc = reinterpret_cast<float *>(sRi + 2 * (BS / 64));  // [4] broadcast scratch
+    float *sG = sX + 2 * S;                                       // [S]     scratch (logZ)
+    float *sRv = sG + S;                                          // [2][NW] arg-max partials
+    int *sRi = reinterpret_cast<int *>(sRv + 2 * NW);             // [2][NW]
+    float *sBc = reinterpret_cast<float *>(sRi + 2 * NW);         // [4] broadcast scratch
     int8_t *sLab = reinterpret_cast<int8_t *>(sBc + 4);           // [T]
 
     const float *sc = p.scores + (size_t)n * p.ld;
@@ -207,52 +235,53 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     float *beta = p.beta + (size_t)n * S;
     float *bmax = p.bmax + (size_t)n * S;
     const size_t sstride = (size_t)N * S;
+    float *qrow = p.qbuf + (size_t)n * ldq;
+    const size_t qstride = (size_t)N * ldq;
     const float blank = p.blank;
 
-    ScoreRing<VW, NR, BS> ring[DEPTH];
-    const int stid = act ? tid : S - 1;          // stash column read by this thread (clamped, always valid)
+    RowRegs<VW, NR, BS> ring[RDEPTH];
 
     // ------------------------------------------------------------------ sweep 1: Log forward
-    if (act) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }
+    if (tid < S) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) ring[d].load(sc + (size_t)(d < T ? d : T - 1) * tstride, cin, tid);
-
-    for (int t0 = 0; t0 < T; t0 += DEPTH) {
+    for (int d = 0; d < RDEPTH; ++d) ring[d].load(sc + (size_t)(d < T ? d : T - 1) * tstride, lim_m, tid);
+    for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int t = t0 + d;
-            if (t < T) {                                   // wave-uniform
-                float *m = sM + (t & 1) * cpad;
-                wait_vm<(DEPTH - 1) * NR>();
-                ring[d].store(m, tid);
-                {
-                    const int tn = t + DEPTH < T ? t + DEPTH : T - 1;
-                    ring[d].load(sc + (size_t)tn * tstride, cin, tid);
-                }
-                lds_barrier();
-                if (act) {
-                    const float *a0 = sA + (t & 1) * S;
-                    const int j = tid;
-                    float x[E];
-                    x[0] = score_at<NB, HB>(m, j, 0, blank) + a0[j];
-                    float mx = x[0];
-                    const int jq = j / NB;
+      for (int d = 0; d < RDEPTH; ++d) {
+        const int t = t0 + d;                                // >= T in the padding iterations
+        float *m = sM + (t & 1) * cpad;
+        ring[d].store(m, tid);
+        ring[d].load(sc + (size_t)(t + RDEPTH < T ? t + RDEPTH : T - 1) * tstride, lim_m, tid);
+        lds_barrier();
+        if (act && t < T) {
+            const float *a0 = sA + (t & 1) * S;
+            const int j = stc;
+            const int jq = j / NB;
+            float x[EPER];
+            float mx = -__builtin_inff();
 #pragma unroll
-                    for (int k = 1; k < E; ++k) {
-                        x[k] = score_at<NB, HB>(m, j, k, blank) + a0[(k - 1) * hi + jq];
-                        mx = maxf(mx, x[k]);
-                    }
-                    float s = xb_expf(x[0] - mx);
+            for (int r = 0; r < EPER; ++r) {
+                const int k = ph * EPER + r;                 // in-edge of state j (0 = stay)
+                const bool val = k < E;
+                const int kc = val ? k : 0;
+                const int src = kc == 0 ? j : (kc - 1) * hi + jq;
+                x[r] = val ? score_at<NB, HB>(m, j, kc, blank) + a0[src] : -__builtin_inff();
+                mx = maxf(mx, x[r]);
+            }
+            mx = cluster_max<LPS>(mx);
+            float ex[EPER];
 #pragma unroll
-                    for (int k = 1; k < E; ++k) s += xb_expf(x[k] - mx);
-                    const float v = mx + xb_logf(s);
-                    sA[((t + 1) & 1) * S + j] = v;
-                    alpha[(size_t)(t + 1) * sstride + j] = v;
-                }
+            for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(x[r] - mx);
+            float s;
+            ordered_sum<LPS, E, EPER>(ex, s);
+            const float v = mx + xb_logf(s);
+            if (ph == 0) {
+                sA[((t + 1) & 1) * S + j] = v;
+                alpha[(size_t)(t + 1) * sstride + j] = v;
             }
         }
+      }
     }
-    wait_vm<0>();
     __syncthreads();
 
     // logZ = logsumexp_j alpha_T[j], summed in order j = 0..S-1
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         }
         __syncthreads();
         const float mx = sBc[0];
-        if (act) sG[tid] = xb_expf(aT[tid] - mx);
+        if (tid < S) sG[tid] = xb_expf(aT[tid] - mx);
         __syncthreads();
         if (tid == 0) {
             float s = sG[0];
@@ -282,114 +311,89 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 #endif
 
     // -------------------------------------------- sweep 2: Log backward + Max backward (fused)
-    float *qrow = p.qbuf + (size_t)n * p.ldq;
-    const size_t qstride = (size_t)N * p.ldq;
     {
-        float aring[DEPTH];
-        // LPS == 1: thread = source state.  LPS == 2: an adjacent lane pair shares a state, lane `ph` owns the
-        // out-edges e = ph*E0 .. (stay first, then new base b = e-1); exps/logs run in both lanes, the ORDERED
-        // logsumexp sum is finished in lane 0 with the partner's terms fetched by DPP in edge order.
-        constexpr int E0 = LPS == 2 ? (E + 1) / 2 : E;
-        const int i = LPS == 2 ? tid >> 1 : tid;
-        const int ph = LPS == 2 ? tid & 1 : 0;
-        const bool act2 = i < S;
-        const int ic = act2 ? i : S - 1;
-        const int kk = ic / hi + 1;
-        const int jb = (ic % hi) * NB;
-        if (act) {
+        if (tid < S) {
             sA[(T & 1) * S + tid] = 0.0f;
             sX[(T & 1) * S + tid] = 0.0f;
             beta[(size_t)T * sstride + tid] = 0.0f;
             bmax[(size_t)T * sstride + tid] = 0.0f;
         }
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int t = T - 1 - d >= 0 ? T - 1 - d : 0;
-            ring[d].load(sc + (size_t)t * tstride, cin, tid);
-            ld_asm(aring[d], alpha + (size_t)t * sstride + ic);
-        }
+        // cluster = source state i; lane ph owns the out-edges e = ph*EPER .. (0 = stay, e >= 1 = new base e-1)
+        const int i = stc;
+        const int kk = i / hi + 1;
+        const int jb = (i % hi) * NB;
         // the Q row of step t is complete once every thread has passed the barrier of step t-1:
         // it is stored (coalesced 16-byte groups) during iteration t-1
         auto store_qrow = [&](int t) {
             const float *src = sQ + (t & 1) * cpad;
             float *dst = qrow + (size_t)t * qstride;
-#pragma unroll
-            for (int r = 0; r < NRQ; ++r) {
-                const int g = (tid + BS * r) * 4;
-                if (g < p.ldq) *reinterpret_cast<f32x4 *>(dst + g) = *reinterpret_cast<const f32x4 *>(src + g);
-            }
+            for (int g = tid * 4; g < ldq; g += BS * 4)
+                *reinterpret_cast<f32x4 *>(dst + g) = *reinterpret_cast<const f32x4 *>(src + g);
         };
-        for (int s0 = 0; s0 < T; s0 += DEPTH) {
+        float aring[RDEPTH];
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int t = T - 1 - (s0 + d);
-                if (t >= 0) {
-                    float *m = sM + (t & 1) * cpad;
-                    float *qs = sQ + (t & 1) * cpad;
-                    wait_vm<(DEPTH - 1) * (NR + 1)>();
-                    ring[d].store(m, tid);
-                    pin(aring[d]);
-                    const float a0 = aring[d];
-                    {
-                        const int tn = t - DEPTH >= 0 ? t - DEPTH : 0;
-                        ring[d].load(sc + (size_t)tn * tstride, cin, tid);
-                        ld_asm(aring[d], alpha + (size_t)tn * sstride + ic);
-                    }
-                    lds_barrier();
-                    if (t + 1 < T) store_qrow(t + 1);
-                    if (act2) {
-                        const float *b1 = sA + ((t + 1) & 1) * S;
-                        const float *m1 = sX + ((t + 1) & 1) * S;
-                        float y[E0], q[E0], mb[E0];
-                        bool val[E0];
+        for (int d = 0; d < RDEPTH; ++d) {
+            const int t = T - 1 - d >= 0 ? T - 1 - d : 0;
+            ring[d].load(sc + (size_t)t * tstride, lim_m, tid);
+            aring[d] = alpha[(size_t)t * sstride + i];
+        }
+        for (int s0 = 0; s0 < Tpad; s0 += RDEPTH) {
 #pragma unroll
-                        for (int r = 0; r < E0; ++r) {
-                            const int e = ph * E0 + r;               // edge: 0 = stay, e >= 1 = new base e-1
-                            val[r] = e < E;
-                            const int ee = val[r] ? e : 0;
-                            const int j = ee == 0 ? ic : jb + ee - 1;
-                            const int k = ee == 0 ? 0 : kk;
-                            const float mv = score_at<NB, HB>(m, j, k, blank);
-                            const float bj = b1[j];
-                            y[r] = mv + bj;
-                            const float xx = ((a0 + mv) + bj) - logZ;
-                            q[r] = xb_logf(xb_expf(xx) + 1e-8f);
-                            mb[r] = m1[j];
-                            if (val[r]) qs[j * E + k] = q[r];
-                        }
-                        float mx = y[0];                             // r = 0 is always a valid edge
-                        float mm = q[0] + mb[0];
+          for (int d = 0; d < RDEPTH; ++d) {
+            const int t = T - 1 - (s0 + d);                  // < 0 in the padding iterations
+            float *m = sM + (t & 1) * cpad;
+            ring[d].store(m, tid);
+            const float a0 = aring[d];
+            {
+                const int tn = t - RDEPTH >= 0 ? t - RDEPTH : 0;
+                ring[d].load(sc + (size_t)tn * tstride, lim_m, tid);
+                aring[d] = alpha[(size_t)tn * sstride + i];
+            }
+            lds_barrier();
+            if (t >= 0 && t + 1 < T) store_qrow(t + 1);
+            if (act && t >= 0) {
+                float *qs = sQ + (t & 1) * cpad;
+                const float *b1 = sA + ((t + 1) & 1) * S;
+                const float *m1 = sX + ((t + 1) & 1) * S;
+                float y[EPER];
+                float mx = -__builtin_inff(), mm = -__builtin_inff();
 #pragma unroll
-                        for (int r = 1; r < E0; ++r)
-                            if (val[r]) { mx = maxf(mx, y[r]); mm = maxf(mm, q[r] + mb[r]); }
-                        if (LPS == 2) {
-                            mx = maxf(mx, dpp_swap(mx));             // max is exact: any order
-                            mm = maxf(mm, dpp_swap(mm));
-                        }
-                        float ex[E0];
-#pragma unroll
-                        for (int r = 0; r < E0; ++r) ex[r] = xb_expf(y[r] - mx);
-                        float s = ex[0];
-#pragma unroll
-                        for (int r = 1; r < E0; ++r) s += ex[r];     // lane 0: edges 0..E0-1 in order
-                        if (LPS == 2) {
-#pragma unroll
-                            for (int r = 0; r < E - E0; ++r) s += dpp_swap(ex[r]);   // then the partner's, in order
-                        }
-                        const float bv = mx + xb_logf(s);
-                        if (ph == 0) {
-                            sA[(t & 1) * S + ic] = bv;
-                            sX[(t & 1) * S + ic] = mm;
-                            beta[(size_t)t * sstride + ic] = bv;
-                            bmax[(size_t)t * sstride + ic] = mm;
-                        }
+                for (int r = 0; r < EPER; ++r) {
+                    const int e = ph * EPER + r;
+                    const bool val = e < E;
+                    const int ee = val ? e : 0;
+                    const int j = ee == 0 ? i : jb + ee - 1;
+                    const int k = ee == 0 ? 0 : kk;
+                    const float mv = score_at<NB, HB>(m, j, k, blank);
+                    const float bj = b1[j];
+                    const float xx = ((a0 + mv) + bj) - logZ;
+                    const float q = xb_logf(xb_expf(xx) + 1e-8f);
+                    y[r] = val ? mv + bj : -__builtin_inff();
+                    if (val) {
+                        qs[j * E + k] = q;
+                        mx = maxf(mx, y[r]);
+                        mm = maxf(mm, q + m1[j]);
                     }
                 }
+                mx = cluster_max<LPS>(mx);
+                mm = cluster_max<LPS>(mm);
+                float ex[EPER];
+#pragma unroll
+                for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(y[r] - mx);
+                float sm;
+                ordered_sum<LPS, E, EPER>(ex, sm);
+                const float bv = mx + xb_logf(sm);
+                if (ph == 0) {
+                    sA[(t & 1) * S + i] = bv;
+                    sX[(t & 1) * S + i] = mm;
+                    beta[(size_t)t * sstride + i] = bv;
+                    bmax[(size_t)t * sstride + i] = mm;
+                }
             }
+          }
         }
         lds_barrier();
         store_qrow(0);
-        wait_vm<0>();
         __syncthreads();
     }
 
@@ -398,84 +402,77 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 #endif
     // --------------------------- sweep 3: Max forward over Q + per-step arg-max of the max-marginals
     {
-        ScoreRing<4, NRQ, BS> qring[DEPTH];
-        float mring[DEPTH];
-        const int ldq = p.ldq;
-        if (act) sX[tid] = 0.0f;
+        if (tid < S) sX[tid] = 0.0f;
+        RowRegs<4, NRQ, BS> qring[RDEPTH];
+        float mring[RDEPTH];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
+        for (int d = 0; d < RDEPTH; ++d) {
             const int t = d < T ? d : T - 1;
             qring[d].load(qrow + (size_t)t * qstride, ldq, tid);
-            ld_asm(mring[d], bmax + (size_t)(t + 1) * sstride + stid);
+            mring[d] = bmax[(size_t)(t + 1) * sstride + stc];
         }
-        const int j = tid;
+        const int j = stc;
         const int jq = j / NB;
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int t0 = 0; t0 < T; t0 += DEPTH) {
+        const int wave = tid >> 6;
+        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int t = t0 + d;
-                if (t < T) {
-                    float *m = sM + (t & 1) * cpad;
-                    wait_vm<(DEPTH - 1) * (NRQ + 1)>();
-                    qring[d].store(m, tid);
-                    pin(mring[d]);
-                    const float m1j = mring[d];
-                    {
-                        const int tn = t + DEPTH < T ? t + DEPTH : T - 1;
-                        qring[d].load(qrow + (size_t)tn * qstride, ldq, tid);
-                        ld_asm(mring[d], bmax + (size_t)(tn + 1) * sstride + stid);
-                    }
-                    lds_barrier();
-                    // finalise the previous step's arg-max (partials were written before this barrier)
-                    if (tid == 0 && t > 0) {
-                        const float *rv = sRv + ((t - 1) & 1) * (BS / 64);
-                        const int *ri = sRi + ((t - 1) & 1) * (BS / 64);
-                        float bv = rv[0];
-                        int bi = ri[0];
-                        for (int w = 1; w < BS / 64; ++w)
-                            if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-                        sLab[t - 1] = (int8_t)(bi % E);
-                    }
-                    float best = -__builtin_inff();
-                    int bestc = 0x7fffffff;
-                    if (act) {
-                        const float *am = sX + (t & 1) * S;
-                        float mm;
-                        {
-                            const float Q = m[j * E];
-                            const float av = am[j];
-                            mm = Q + av;
-                            best = (av + Q) + m1j;
-                            bestc = j * E;
-                        }
+          for (int d = 0; d < RDEPTH; ++d) {
+            const int t = t0 + d;                            // >= T in the padding iterations
+            float *m = sM + (t & 1) * cpad;
+            qring[d].store(m, tid);
+            const float m1j = mring[d];
+            {
+                const int tn = t + RDEPTH < T ? t + RDEPTH : T - 1;
+                qring[d].load(qrow + (size_t)tn * qstride, ldq, tid);
+                mring[d] = bmax[(size_t)(tn + 1) * sstride + stc];
+            }
+            lds_barrier();
+            // finalise the previous step's arg-max (partials were written before this barrier)
+            if (tid == 0 && t > 0 && t <= T) {
+                const float *rv = sRv + ((t - 1) & 1) * NW;
+                const int *ri = sRi + ((t - 1) & 1) * NW;
+                float bv = rv[0];
+                int bi = ri[0];
+                for (int w = 1; w < NW; ++w)
+                    if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+                sLab[t - 1] = (int8_t)(bi % E);
+            }
+            if (t < T) {                                     // wave-uniform
+            float best = -__builtin_inff();
+            int bestc = 0x7fffffff;
+            if (act) {
+                const float *am = sX + (t & 1) * S;
+                float mm = -__builtin_inff();
 #pragma unroll
-                        for (int k = 1; k < E; ++k) {
-                            const int src = (k - 1) * hi + jq;
-                            const float Q = m[j * E + k];
-                            const float av = am[src];
-                            mm = maxf(mm, Q + av);
-                            const float scv = (av + Q) + m1j;
-                            if (scv > best) { best = scv; bestc = j * E + k; }
-                        }
-                        sX[((t + 1) & 1) * S + j] = mm;
-                    }
-                    wave_argmax(best, bestc);
-                    if (lane == 63) {
-                        sRv[(t & 1) * (BS / 64) + wave] = best;
-                        sRi[(t & 1) * (BS / 64) + wave] = bestc;
+                for (int r = 0; r < EPER; ++r) {
+                    const int k = ph * EPER + r;             // in-edge of state j, increasing flat index
+                    if (k < E) {
+                        const int src = k == 0 ? j : (k - 1) * hi + jq;
+                        const float Q = m[j * E + k];
+                        const float av = am[src];
+                        mm = maxf(mm, Q + av);
+                        const float scv = (av + Q) + m1j;
+                        if (scv > best) { best = scv; bestc = j * E + k; }
                     }
                 }
+                mm = cluster_max<LPS>(mm);
+                if (ph == 0) sX[((t + 1) & 1) * S + j] = mm;
             }
+            wave_argmax(best, bestc);
+            if (lane == 63) {
+                sRv[(t & 1) * NW + wave] = best;
+                sRi[(t & 1) * NW + wave] = bestc;
+            }
+            }
+          }
         }
-        wait_vm<0>();
         __syncthreads();
-        if (tid == 0) {
-            const float *rv = sRv + ((T - 1) & 1) * (BS / 64);
-            const int *ri = sRi + ((T - 1) & 1) * (BS / 64);
+        if (tid == 0 && Tpad == T) {                             // otherwise a padding iteration already did it
+            const float *rv = sRv + ((T - 1) & 1) * NW;
+            const int *ri = sRi + ((T - 1) & 1) * NW;
             float bv = rv[0];
             int bi = ri[0];
-            for (int w = 1; w < BS / 64; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
             sLab[T - 1] = (int8_t)(bi % E);
         }
@@ -486,7 +483,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     if (p.labels)
         for (int t = tid; t < T; t += BS) p.labels[(size_t)n * T + t] = sLab[t];
     if (p.seq || p.seq_len) {
-        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints, sM (2*BS*NR*VW floats) is free now
+        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints; the row ring is free now (size checked on host)
         const int per = (T + BS - 1) / BS;
         const int lo = tid * per, hiT = (lo + per < T) ? lo + per : T;
         int cnt = 0;
@@ -515,36 +512,64 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 template <int NB, int BS, int LPS>
 hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
+    // must mirror the kernel's LDS carve
     const int cpad = BS * 8;
-    size_t lds = sizeof(float) * (4 * (size_t)cpad + 6 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
+    size_t lds = sizeof(float) * (4 * (size_t)cpad + 5 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
                  sizeof(float) * 4 + (size_t)p.T;
     lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(p.N), block(BS);
-#define XB_LAUNCH(VW, HB) hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB, LPS>), grid, block, lds, stream, p)
+#define XB_LAUNCH(VW, HB)                                                                                          \
+    do {                                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_decode_kernel<NB, BS, VW, HB, LPS>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB, LPS>), grid, block, lds, stream, p);                 \
+    } while (0)
     if (p.has_blank) {
-        if (vw == 4) XB_LAUNCH(4, true); else if (vw == 2) XB_LAUNCH(2, true); else XB_LAUNCH(1, true);
+        if (vw == 4) XB_LAUNCH(4, true); else XB_LAUNCH(1, true);
     } else {
-        if (vw == 4) XB_LAUNCH(4, false); else if (vw == 2) XB_LAUNCH(2, false); else XB_LAUNCH(1, false);
+        if (vw == 4) XB_LAUNCH(4, false); else XB_LAUNCH(1, false);
     }
 #undef XB_LAUNCH
     return hipGetLastError();
 }
 
-// two lanes per state in sweep 2 while the doubled block stays within 256 threads (measured on MI355X at
-// N = 512: nb = 5 gains 17 %, a 512-thread block for nb = 6 loses 10 % to barrier / arg-max overheads)
+// Block = smallest of 64/128/256/512/1024 threads that holds LPS lanes for each of the S states.
+template <int NB, int LPS>
+hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
+{
+    const int need = LPS * p.S;
+    if (need <= 64) return launch_nb_bs<NB, 64, LPS>(p, vw, stream);
+    if (need <= 128) return launch_nb_bs<NB, 128, LPS>(p, vw, stream);
+    if (need <= 256) return launch_nb_bs<NB, 256, LPS>(p, vw, stream);
+    if (need <= 512) return launch_nb_bs<NB, 512, LPS>(p, vw, stream);
+    if (LPS == 1 && need <= 1024) return launch_nb_bs<NB, 1024, 1>(p, vw, stream);
+    return hipErrorInvalidValue;
+}
 template <int NB>
 hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    if (2 * p.S <= 64) return launch_nb_bs<NB, 64, 2>(p, vw, stream);
-    if (2 * p.S <= 128) return launch_nb_bs<NB, 128, 2>(p, vw, stream);
-    if (2 * p.S <= 256) return launch_nb_bs<NB, 256, 2>(p, vw, stream);
-    if (p.S <= 256) return launch_nb_bs<NB, 256, 1>(p, vw, stream);
-    return launch_nb_bs<NB, 1024, 1>(p, vw, stream);
+    switch (xb::decode_lanes_per_state(p.S)) {
+    case 4: return launch_nb_lps<NB, 4>(p, vw, stream);
+    case 2: return launch_nb_lps<NB, 2>(p, vw, stream);
+    default: return launch_nb_lps<NB, 1>(p, vw, stream);
+    }
 }
 
 }  // namespace
 
 namespace xb {
+
+int decode_lanes_per_state(int S)
+{
+    if (const char *e = getenv("XB_DECODE_LPS")) {
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4) && v * S <= 512) return v;
+    }
+    // measured on MI355X (N = 512, T = 2000): two lanes per state win while the block stays <= 256 threads
+    // (S = 64: 4.7 vs 5.0 ms, S = 125: 5.5 vs 6.8 ms); at S = 216 a 512-thread block loses (9.7 vs 8.5 ms)
+    return 2 * S <= 256 ? 2 : 1;
+}
 
 // Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:
 //   S = NB^state_len <= 1024, cin = S*(NB+1) or S*NB, ld >= cin (the pack scratch of BS+1 ints always
@@ -559,7 +584,6 @@ hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
     const uintptr_t a = reinterpret_cast<uintptr_t>(p.scores);
     // vector loads may run into the row's padding columns (ld >= cin rounded up), never past the row
     if (p.ld % 4 == 0 && p.ld >= ((p.cin + 3) & ~3) && a % 16 == 0) vw = 4;
-    else if (p.ld % 2 == 0 && p.ld >= ((p.cin + 1) & ~1) && a % 8 == 0) vw = 2;
     switch (p.nb) {
     case 4: return launch_nb<4>(p, vw, stream);
     case 5: return launch_nb<5>(p, vw, stream);

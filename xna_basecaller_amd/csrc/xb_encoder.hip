@@ -413,10 +413,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const unsigned target = (unsigned)members * (unsigned)(s - p.s_begin);
                     const unsigned long long t0 = __builtin_readcyclecounter();
                     int ok = 1;
-                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                            __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES) {
+                    // the counter is polled back to back (one L2 round trip per poll); the error word and the
+                    // timeout are looked at every 64th poll only
+                    for (unsigned spins = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+                        if ((spins & 63u) == 0 &&
+                            (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                             __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES)) {
                             __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             ok = 0;
                             break;
