@@ -12,6 +12,7 @@
 // Gates, cell state and activations are fp32 VALU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "xb_internal.h"
 
@@ -20,6 +21,7 @@ namespace {
 using xb::half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
@@ -126,6 +128,60 @@ __global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
 // ======================================================================================
 constexpr int GBM = 256, GBN = 256, GBK = 32, GTHREADS = 512;
 
+
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b & 7), each with its own
+// L2.  The 32 blocks an XCD runs side by side are made one super-tile of SM x SN output tiles, so an A row panel is
+// fetched by SN neighbours and a B panel by SM neighbours out of the SAME L2 instead of by all eight.
+__device__ __forceinline__ bool gemm_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
+{
+    const int MT = (p.M + GBM - 1) / GBM, NT = (p.Nn + GBN - 1) / GBN;
+    const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
+    const int ngroups = (NT + SN - 1) / SN, msup = (MT + SM - 1) / SM;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int q = (j >> 5) * 8 + xcd, w = j & 31;          // super-tile id, slot in it
+    if (q >= msup * ngroups || w >= SM * SN) return false;
+    const int mt = (q / ngroups) * SM + w / SN, nt = (q % ngroups) * SN + w % SN;
+    if (mt >= MT || nt >= NT) return false;
+    m0 = mt * GBM;
+    n0 = nt * GBN;
+    return true;
+}
+
+// epilogue shared by the GEMM kernels: a wave holds 4 x 2 accumulator tiles of 32x32 (rows wm*128.., cols wn*64..);
+// a lane holds column (lane & 31) and 16 rows of each tile
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const floatx16 (&acc)[4][2], int m0, int n0,
+                                              int wm, int wn, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.Nn) continue;
+            const float bias = p.bias ? p.bias[n] : 0.0f;
+            int ocol = n;
+            if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const float v = acc[i][j][r] + bias;
+                if (EPI == xb::EPI_BIAS_F32) {
+                    p.out_f32[(size_t)m * p.ldc + n] = v;
+                } else if (EPI == xb::EPI_SILU_SPLIT) {
+                    half_t hi, lo;
+                    split_f16(silu(v), hi, lo);
+                    p.out_hi[(size_t)m * p.ldc + n] = hi;
+                    p.out_lo[(size_t)m * p.ldc + n] = lo;
+                } else {
+                    p.out_f32[(size_t)m * p.ldc + ocol] = p.scale * fast_tanh(v);
+                    if (p.expand && n % p.nb == 0) p.out_f32[(size_t)m * p.ldc + ocol - 1] = p.blank;
+                }
+            }
+        }
+}
+
 struct Stage2 { uint4 v[2]; };
 
 // 256 rows x 32 halves of one operand part = 1024 cells of 16 B; thread `tid` moves cells tid, tid+512
@@ -160,7 +216,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void gemm_kernel(xb::GemmParams p)
     uint4(*lds)[NPART][GBM * 4] = reinterpret_cast<uint4(*)[NPART][GBM * 4]>(smem_raw);   // [2][NPART][1024]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    int m0, n0;
+    if (!gemm_tile_origin(p, m0, n0)) return;
     const int nk = p.K / GBK;
 
     Stage2 sAh, sAl, sBh, sBl;
@@ -235,34 +292,343 @@ __global__ __launch_bounds__(GTHREADS, 2) void gemm_kernel(xb::GemmParams p)
 #undef XB_LOAD_REGS
 #undef XB_WRITE_LDS
 
-    // epilogue: lane holds column n (lane & 31) and 16 rows per tile
+    gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ======================================================================================
+// gemm8_kernel: the same 256x256x32 split-fp16 tile, scheduled as a two-group ping-pong
+// (cdna_hip_programming.md "256^2 8-phase template", adapted to 4-byte hi+lo elements).
+//  * Operand tiles are staged by LDS-DMA in four 16-KiB half-tiles per k-tile (SA0, SA1 = block rows 0..127 /
+//    128..255 of A; SB0, SB1 likewise for B), two 1-KiB pieces (hi, lo) per wave and half-tile, source cells
+//    pre-swizzled so the LDS image is the XOR-swizzled one the fragment reads expect.  No staging registers.
+//  * A k-tile is four phases, one 64x32 output quadrant of the wave each (12 MFMAs = 2 M-tiles x 2 k-steps x 3
+//    products):  q0 (A0,B0)  q1 (A0,B1)  q2 (A1,B1)  q3 (A1,B0).  Phase = {fragment reads + DMA issue} barrier
+//    {MFMAs} barrier.  Waves 4-7 (wr = 1) run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA
+//    cluster while the other reads LDS / issues DMA.
+//  * DMA order per tile t:  q0: SA1(t+1)   q2: SB0(t+2), SB1(t+2)   q3: SA0(t+2), then ONE counted wait
+//    (vmcnt = the 6 pieces issued after SA1(t+1)) before q3's first barrier; tile t+1 is first read two barriers later.
+//    Re-staging rules (WAR): a half-tile slot is re-staged two phases after its last fragment read, or one phase after
+//    when that read phase retires its reads (lgkmcnt(0)) before its first barrier (q1 for SB, q2 for SA).
+// ======================================================================================
+__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+#define G8_BARRIER()                                   \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        __builtin_amdgcn_s_barrier();                  \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+
+template <int EPI, int NSPLIT>
+__global__ __launch_bounds__(GTHREADS) void gemm8_kernel(xb::GemmParams p)
+{
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    constexpr int PARTB = 128 * 64;            // one part (hi or lo) of a half-tile: 128 rows x 32 halves
+    constexpr int HTB = NP * PARTB;            // half-tile bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // [2 dbuf][4 half-tiles][HTB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    int m0, n0;
+    if (!gemm_tile_origin(p, m0, n0)) return;
+    const int nk = p.K / GBK;
+    const half_t *a_hi = p.a_hi, *a_lo = p.a_lo, *b_hi = p.b_hi, *b_lo = p.b_lo;
+
+    // ---- DMA source offsets (elements): lane i of wave w fills slot i of rows 16w..16w+15 of a half-tile part:
+    //      row 16w + (i >> 2), LDS cell (i & 3) <- source cell (i & 3) ^ ((row >> 2) & 3)
+    size_t offs[4];
+    {
+        const int drow = 16 * wid + (lane >> 2), dch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+        const int Mlast = p.M - 1, Nlast = p.Nn - 1;
+        int r;
+        r = m0 + drow;        offs[0] = (size_t)(r > Mlast ? Mlast : r) * p.lda + dch;
+        r = m0 + 128 + drow;  offs[1] = (size_t)(r > Mlast ? Mlast : r) * p.lda + dch;
+        r = n0 + drow;        offs[2] = (size_t)(r > Nlast ? Nlast : r) * p.ldb + dch;
+        r = n0 + 128 + drow;  offs[3] = (size_t)(r > Nlast ? Nlast : r) * p.ldb + dch;
+    }
+    unsigned char *const wdst = smem_raw + wid * 1024;
+#define G8_STAGE(h, t)                                                                          \
+    do {                                                                                        \
+        unsigned char *dst_ = wdst + ((((t) & 1) * 4 + (h)) * HTB);                             \
+        const size_t o_ = offs[(h)] + (size_t)(t) * GBK;                                        \
+        dma16(((h) < 2 ? a_hi : b_hi) + o_, dst_);                                              \
+        if (NP == 2) dma16(((h) < 2 ? a_lo : b_lo) + o_, dst_ + PARTB);                         \
+    } while (0)
+
+    // ---- fragment read offsets (bytes): row (lane & 31) of a 32-row tile, cell (2 ks + (lane >> 5)) ^ ((row >> 2) & 3)
+    unsigned la[2];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int ks = 0; ks < 2; ++ks)
+        la[ks] = (unsigned)((lane & 31) * 64 + (((2 * ks + (lane >> 5)) ^ ((lane >> 2) & 3)) * 16));
+    const unsigned char *const fragA = smem_raw + wr * HTB;                                  // SA_wr
+    const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
+
+    half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];     // A: [tile of the current M half][ks];  B: [n tile][ks]
+#define G8_READ_A(d, mh)                                                                                  \
+    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {    \
+        const unsigned char *q_ = fragA + (d) * 4 * HTB + ((mh) * 2 + i2) * 2048 + la[ks];                \
+        ah[i2][ks] = *reinterpret_cast<const half8 *>(q_);                                                \
+        if (NP == 2) al[i2][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                           \
+    }
+#define G8_READ_B(d, n)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+        const unsigned char *q_ = fragB + (d) * 4 * HTB + (n) * 2048 + la[ks];                            \
+        bh[(n)][ks] = *reinterpret_cast<const half8 *>(q_);                                               \
+        if (NP == 2) bl[(n)][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                          \
+    }
+#define G8_MFMA(mh, n)                                                                                    \
+    do {                                                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+            if (NP == 2) {                                                                                \
+                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bl[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+            }                                                                                             \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                    \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+        }                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
+    } while (0)
+
+    floatx16 acc[4][2];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + wn * (WN * 32) + j * 32 + (lane & 31);
-            if (n >= p.Nn) continue;
-            const float bias = p.bias ? p.bias[n] : 0.0f;
-            int ocol = n;
-            if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (WM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                const float v = acc[i][j][r] + bias;
-                if (EPI == xb::EPI_BIAS_F32) {
-                    p.out_f32[(size_t)m * p.ldc + n] = v;
-                } else if (EPI == xb::EPI_SILU_SPLIT) {
-                    half_t hi, lo;
-                    split_f16(silu(v), hi, lo);
-                    p.out_hi[(size_t)m * p.ldc + n] = hi;
-                    p.out_lo[(size_t)m * p.ldc + n] = lo;
-                } else {
-                    p.out_f32[(size_t)m * p.ldc + ocol] = p.scale * fast_tanh(v);
-                    if (p.expand && n % p.nb == 0) p.out_f32[(size_t)m * p.ldc + ocol - 1] = p.blank;
-                }
-            }
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- prologue: tile 0 complete; SB0(1), SB1(1), SA0(1) in flight
+    G8_STAGE(0, 0);
+    G8_STAGE(1, 0);
+    G8_STAGE(2, 0);
+    G8_STAGE(3, 0);
+    if (nk > 1) {
+        G8_STAGE(2, 1);
+        G8_STAGE(3, 1);
+        G8_STAGE(0, 1);
+        if (NP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G8_BARRIER();
+    if (wr == 1) G8_BARRIER();          // the second wave group runs one barrier behind the first
+
+#define G8_TILE(d, t)                                                                       \
+    do {                                                                                    \
+        /* q0 */                                                                            \
+        G8_READ_B(d, 0);                                                                    \
+        G8_READ_A(d, 0);                                                                    \
+        if ((t) + 1 < nk) G8_STAGE(1, (t) + 1);                                             \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(0, 0);                                                                      \
+        G8_BARRIER();                                                                       \
+        /* q1 */                                                                            \
+        G8_READ_B(d, 1);                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(0, 1);                                                                      \
+        G8_BARRIER();                                                                       \
+        /* q2 */                                                                            \
+        G8_READ_A(d, 1);                                                                    \
+        if ((t) + 2 < nk) {                                                                 \
+            G8_STAGE(2, (t) + 2);                                                           \
+            G8_STAGE(3, (t) + 2);                                                           \
+        }                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(1, 1);                                                                      \
+        G8_BARRIER();                                                                       \
+        /* q3 */                                                                            \
+        if ((t) + 2 < nk) {                                                                 \
+            G8_STAGE(0, (t) + 2);                                                           \
+            if (NP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   \
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
+        } else {                                                                            \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+        }                                                                                   \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(1, 0);                                                                      \
+        G8_BARRIER();                                                                       \
+    } while (0)
+
+    for (int t = 0; t < nk; t += 2) {
+        G8_TILE(0, t);
+        if (t + 1 < nk) G8_TILE(1, t + 1);
+    }
+    if (wr == 0) G8_BARRIER();          // matches the extra barrier of the second group
+#undef G8_TILE
+#undef G8_MFMA
+#undef G8_READ_A
+#undef G8_READ_B
+#undef G8_STAGE
+
+    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int EPI, int NSPLIT>
+__global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
+{
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    constexpr int PARTB = 128 * 64;            // one part (hi or lo) of a half-tile: 128 rows x 32 halves
+    constexpr int HTB = NP * PARTB;            // half-tile bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // [2 dbuf][4 half-tiles][HTB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    int m0, n0;
+    if (!gemm_tile_origin(p, m0, n0)) return;
+    const int nk = p.K / GBK;
+
+    // ---- staging source: wave-uniform tile bases (SGPRs) + 32-bit lane byte offsets.  Lane i of wave w moves slot i of rows
+    //      16w..16w+15 of a half-tile part: row 16w + (i >> 2), LDS cell (i & 3) <- source cell (i & 3) ^ ((row >> 2) & 3).
+    //      Rows past the matrix end are clamped to the last row (their products land in rows / columns never stored).
+    unsigned offs[4];
+    {
+        const int drow = 16 * wid + (lane >> 2), dch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+        const int Mrem = p.M - 1 - m0, Nrem = p.Nn - 1 - n0;      // last valid row, relative to the tile
+        int r;
+        r = drow;        offs[0] = (unsigned)(((r > Mrem ? Mrem : r) * p.lda + dch) * 2);
+        r = 128 + drow;  offs[1] = (unsigned)(((r > Mrem ? Mrem : r) * p.lda + dch) * 2);
+        r = drow;        offs[2] = (unsigned)(((r > Nrem ? Nrem : r) * p.ldb + dch) * 2);
+        r = 128 + drow;  offs[3] = (unsigned)(((r > Nrem ? Nrem : r) * p.ldb + dch) * 2);
+    }
+    const unsigned char *const tA_hi = reinterpret_cast<const unsigned char *>(p.a_hi + (size_t)m0 * p.lda);
+    const unsigned char *const tA_lo = reinterpret_cast<const unsigned char *>(p.a_lo + (size_t)m0 * p.lda);
+    const unsigned char *const tB_hi = reinterpret_cast<const unsigned char *>(p.b_hi + (size_t)n0 * p.ldb);
+    const unsigned char *const tB_lo = reinterpret_cast<const unsigned char *>(p.b_lo + (size_t)n0 * p.ldb);
+    unsigned char *const wdst = smem_raw + wid * 1024;
+    // register staging: st[h][part] = this lane's 16 bytes of the wave's piece of half-tile h.  Loaded for tile t+2 at
+    // phase (t, h), written to LDS (tile t+1's bytes, loaded one tile earlier) just before that.
+    u32x4 st[4][NP];
+    unsigned char *const ldst = wdst + lane * 16;
+#define G8_LOAD(h, t)                                                                           \
+    do {                                                                                        \
+        const size_t kb_ = (size_t)(t) * (GBK * 2);                                             \
+        st[(h)][0] = *reinterpret_cast<const u32x4 *>(((h) < 2 ? tA_hi : tB_hi) + kb_ + offs[(h)]); \
+        if (NP == 2) st[(h)][1] = *reinterpret_cast<const u32x4 *>(((h) < 2 ? tA_lo : tB_lo) + kb_ + offs[(h)]); \
+    } while (0)
+#define G8_WRITE(h, t)                                                                          \
+    do {                                                                                        \
+        unsigned char *dst_ = ldst + ((((t) & 1) * 4 + (h)) * HTB);                             \
+        *reinterpret_cast<u32x4 *>(dst_) = st[(h)][0];                                          \
+        if (NP == 2) *reinterpret_cast<u32x4 *>(dst_ + PARTB) = st[(h)][1];                     \
+    } while (0)
+
+    // ---- fragment read offsets (bytes): row (lane & 31) of a 32-row tile, cell (2 ks + (lane >> 5)) ^ ((row >> 2) & 3)
+    unsigned la[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        la[ks] = (unsigned)((lane & 31) * 64 + (((2 * ks + (lane >> 5)) ^ ((lane >> 2) & 3)) * 16));
+    const unsigned char *const fragA = smem_raw + wr * HTB;                                  // SA_wr
+    const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
+
+    half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];     // A: [tile of the current M half][ks];  B: [n tile][ks]
+#define G8_READ_A(d, mh)                                                                                  \
+    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {    \
+        const unsigned char *q_ = fragA + (d) * 4 * HTB + ((mh) * 2 + i2) * 2048 + la[ks];                \
+        ah[i2][ks] = *reinterpret_cast<const half8 *>(q_);                                                \
+        if (NP == 2) al[i2][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                           \
+    }
+#define G8_READ_B(d, n)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+        const unsigned char *q_ = fragB + (d) * 4 * HTB + (n) * 2048 + la[ks];                            \
+        bh[(n)][ks] = *reinterpret_cast<const half8 *>(q_);                                               \
+        if (NP == 2) bl[(n)][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                          \
+    }
+#define G8_MFMA(mh, n)                                                                                    \
+    do {                                                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+            if (NP == 2) {                                                                                \
+                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bl[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+            }                                                                                             \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                    \
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+        }                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
+    } while (0)
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- prologue: tile 0 in LDS, tile 1 in flight into the staging registers
+#pragma unroll
+    for (int h = 0; h < 4; ++h) G8_LOAD(h, 0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) G8_WRITE(h, 0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) G8_LOAD(h, nk > 1 ? 1 : 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G8_BARRIER();
+    if (wr == 1) G8_BARRIER();          // the second wave group runs one barrier behind the first
+
+    // phase (t, q): fragment reads of quadrant q; write half-tile q of tile t+1 into the other buffer (its last reads were
+    // in tile t-1); reload the staging registers with half-tile q of tile t+2; retire the LDS operations; barrier.
+#define G8_MOVE(q, t)                                                                       \
+    do {                                                                                    \
+        G8_WRITE(q, (t) + 1);                                                               \
+        __builtin_amdgcn_sched_barrier(0);      /* reload the SAME registers after the write */ \
+        G8_LOAD(q, (t) + 2 < nk ? (t) + 2 : nk - 1);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+    } while (0)
+#define G8_TILE(d, t)                                                                       \
+    do {                                                                                    \
+        G8_READ_B(d, 0);                                                                    \
+        G8_READ_A(d, 0);                                                                    \
+        G8_MOVE(0, t);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(0, 0);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_READ_B(d, 1);                                                                    \
+        G8_MOVE(1, t);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(0, 1);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_READ_A(d, 1);                                                                    \
+        G8_MOVE(2, t);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(1, 1);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_MOVE(3, t);                                                                      \
+        G8_BARRIER();                                                                       \
+        G8_MFMA(1, 0);                                                                      \
+        G8_BARRIER();                                                                       \
+    } while (0)
+
+    // The tile body is branch-free so that the compiler's vmcnt bookkeeping stays exact (three half-tiles in flight):
+    // past the end it re-loads the last tile (L2 hits) and writes it into the buffer nobody reads any more.
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        G8_TILE(0, t);
+        G8_TILE(1, t + 1);
+    }
+    if (t < nk) G8_TILE(0, t);
+    if (wr == 0) G8_BARRIER();          // matches the extra barrier of the second group
+#undef G8_MOVE
+#undef G8_LOAD
+#undef G8_WRITE
+#undef G8_TILE
+#undef G8_MFMA
+#undef G8_READ_A
+#undef G8_READ_B
+
+    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);
 }
 
 // ======================================================================================
@@ -297,7 +663,6 @@ __device__ __forceinline__ void dma16_sc1(const void *g, void *lds_wave_base)
 }
 
 // 16-byte write-through store (the `s_nop 1` keeps the data registers intact until the store has read them)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_sc1(void *g, uint4 v)
 {
     const u32x4 d = {v.x, v.y, v.z, v.w};
@@ -616,8 +981,39 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 template <int EPI>
 hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
 {
-    dim3 grid((p.Nn + GBN - 1) / GBN, (p.M + GBM - 1) / GBM), block(GTHREADS);
+    const int MT = (p.M + GBM - 1) / GBM, NT = (p.Nn + GBN - 1) / GBN;
+    const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
+    const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see the tile order in gemm_kernel
+    dim3 grid(8 * 32 * ((supers + 7) / 8)), block(GTHREADS);
     const size_t lds = (size_t)2 * (p.nsplit == 3 ? 4 : 2) * GBM * 4 * sizeof(uint4);
+    static const int variant = [] {                 // XB_GEMM_KERNEL=1: the register-staged kernel (A/B runs)
+        const char *e = getenv("XB_GEMM_KERNEL");
+        return e ? atoi(e) : 8;
+    }();
+    if (variant == 8) {
+        if (p.nsplit == 3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm8r_kernel<EPI, 3>), grid, block, lds, stream, p);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm8r_kernel<EPI, 1>), grid, block, lds, stream, p);
+        }
+        return hipGetLastError();
+    }
+    if (variant == 9) {
+        if (p.nsplit == 3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<EPI, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm8_kernel<EPI, 3>), grid, block, lds, stream, p);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<EPI, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((gemm8_kernel<EPI, 1>), grid, block, lds, stream, p);
+        }
+        return hipGetLastError();
+    }
     if (p.nsplit == 3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
