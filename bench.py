@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--nbase", type=int, default=5, choices=[4, 5, 6])
     ap.add_argument("--features", type=int, default=768)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16", "f16f8"])
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--lstm-mode", type=int, default=0)
     args = ap.parse_args()
@@ -82,7 +82,7 @@ def main():
     nb, L, N, F = args.nbase, args.chunksize, args.batch, args.features
     alphabet = "NACGTXY"[:nb + 1]
     S, E = nb ** 3, nb + 1
-    prec = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16}[args.precision]
+    prec = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8}[args.precision]
     ctx = _lib.Context(local, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=prec, lstm_mode=args.lstm_mode)
     sd = seeded_weights(F, nb)
     ctx.load_state_dict(sd)
@@ -141,11 +141,12 @@ def main():
     flop_launch = 2.0 * (4 * F) * F * T * N
     rec_avg_s = 1e-3 * rec_ms / max(rec_launches, 1)
     rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
-    roofline = {"kernel": "lstm_kernel<%d,%d>" % (F // 16, 3 if prec == 0 else 1), "bound": "mfma",
+    roofline = {"kernel": "lstm_kernel<%d,%d>" % (F // 16, {0: 3, 1: 1, 2: 2}[prec]), "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches,
-                "note": "algorithmic fp32-equivalent FLOPs; the split-fp16 path issues 3 MFMA products per FLOP pair"}
+                "note": "algorithmic fp32-equivalent FLOPs; f16x3 issues 3 fp16 MFMA products per FLOP pair, "
+                        "f16f8 one fp16 product + one block-scaled FP8 MFMA (2x rate) for both corrections"}
     # ---- CRF decode: HBM roofline (the north-star target) -------------------------------------------------
     dec_ms, dec_launches = stages["decode"]
     a_dec = float(T) * N * (3 * S * E * 4 + 7 * S * 4 + 1)        # A_dec bytes per launch
@@ -160,7 +161,9 @@ def main():
         "metric": "raw signal samples/sec basecalled, chunksize 10k", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (split-f16x3 MFMA, f32 accumulate; CRF decode f32)" if prec == 0 else "f16 MFMA, f32 accumulate; CRF decode f32",
+        "dtype": {0: "f32 (split-f16x3 MFMA, f32 accumulate; CRF decode f32)",
+                  1: "f16 MFMA, f32 accumulate; CRF decode f32",
+                  2: "f32 (f16 MFMA + FP8 block-scaled correction MFMA, f32 accumulate; CRF decode f32)"}[prec],
         "data": "synthetic N(0,1) signal chunks generated in HBM; seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout",
         "config": {"workload": "BASELINE configs[%d]: %d-base CRF (S=%d, C=%d), chunksize %d, batch %d per GPU, features %d"
                                % (1 if nb == 5 else 2, nb, S, S * E, L, N, F),

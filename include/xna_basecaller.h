@@ -50,8 +50,9 @@ typedef enum xb_status {
 
 /* Arithmetic of the dense projections (Conv1d k19, LSTM, Linear). */
 typedef enum xb_precision {
-    XB_PREC_F16X3 = 0,        /* split-fp16 MFMA, 3 products, fp32 accumulate: |score err| ~1e-5 */
-    XB_PREC_F16 = 1           /* single fp16 MFMA, fp32 accumulate (the reference's model.half()) */
+    XB_PREC_F16X3 = 0,        /* split-fp16 MFMA, 3 products, fp32 accumulate: |score err| ~3e-6 */
+    XB_PREC_F16 = 1,          /* single fp16 MFMA, fp32 accumulate (the reference's model.half()): ~1e-3 */
+    XB_PREC_F16F8 = 2         /* fp16 main product + both correction products on the block-scaled FP8 MFMA: ~4e-5 */
 } xb_precision;
 
 /*

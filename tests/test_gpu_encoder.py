@@ -121,3 +121,44 @@ def test_persistent_handoff_is_placement_independent(monkeypatch):
     assert np.array_equal(outs["step"], outs["persist_spread"])
     ref = oracle.encode(x[:4], sd, 768, 6, 3)
     assert np.abs(outs["persist"][:, :4] - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("features,nb,L,N", [(32, 6, 500, 5), (64, 5, 600, 3), (96, 4, 800, 70), (128, 6, 400, 2)])
+def test_encoder_f16f8_vs_oracle(features, nb, L, N):
+    """precision = f16f8: fp16 main product, both correction products on the block-scaled FP8 MFMA.
+    Numerical model (tools/../DESIGN.md): |score error| ~4e-5 at features 768, an order below the north-star 1e-3."""
+    keys, shapes = encoder_shapes(features, nb)
+    sd = seeded_state_dict(keys, shapes, seed=features + nb)
+    x = np.random.default_rng(L).standard_normal((N, L)).astype(np.float32)
+    ref = oracle.encode(x, sd, features, nb, 3)
+    outs = []
+    for mode in (1, 2):
+        ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        got = ctx.encode(x)
+        err = np.abs(got - ref).max()
+        assert err < 2e-4, err
+        outs.append(got)
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_encoder_f16f8_full_size():
+    """features 768, several groups with a ragged tail: persistent == per-step bit for bit, oracle within 2e-4,
+    and large activations (conv output beyond the e4m3 range of the q8 image) only lose the correction, not the value."""
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))["full"]
+    sd = seeded_state_dict(meta["keys"], meta["shapes"], meta["seed"])
+    N, L = 150, 400
+    x = np.random.default_rng(11).standard_normal((N, L)).astype(np.float32)
+    x[3] *= 40.0                                            # a badly normalised chunk
+    outs = {}
+    for name, mode in [("step", 1), ("persist", 2)]:
+        ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        outs[name] = ctx.encode(x)
+        ctx.close()
+    assert np.array_equal(outs["step"], outs["persist"])
+    ref = oracle.encode(x[:4], sd, 768, 6, 3)
+    err = np.abs(outs["persist"][:, :4] - ref)
+    assert err[:, :3].max() < 2e-4, err[:, :3].max()
+    assert err[:, 3].max() < 1e-3, err[:, 3].max()

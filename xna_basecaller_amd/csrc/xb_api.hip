@@ -50,6 +50,7 @@ struct xb_ctx {
     float *lbias[5] = {};
     half_t *wl_hi = nullptr, *wl_lo = nullptr;
     float *bl = nullptr;
+    int w3_exp = 0, wih_exp[5] = {}, whh_exp[5] = {}, wl_exp = 0;   // q8 exponents (XB_PREC_F16F8)
 
     // activations / workspaces
     float *d_signal = nullptr;
@@ -158,16 +159,56 @@ int64_t expected_size(const xb_ctx *c, const std::string &name)
     return -1;
 }
 
-void split_rows(const float *src, int rows, int cols, int ld, std::vector<half_t> &hi, std::vector<half_t> &lo)
+// OCP e4m3 (fn) encoding of x: round to nearest even, saturating at +-448 (the MFMA's operand format on gfx950)
+uint8_t f32_to_e4m3(float x)
+{
+    const uint8_t sign = std::signbit(x) ? 0x80 : 0x00;
+    const float a = std::fabs(x);
+    if (!(a == a)) return sign | 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < 0.015625f) {                                   // subnormal: steps of 2^-9
+        const int q = (int)std::nearbyint(std::ldexp(a, 9));
+        return sign | (uint8_t)q;                          // q == 8 is the smallest normal, encoded 0x08 as well
+    }
+    int ex;
+    (void)std::frexp(a, &ex);                              // a = m * 2^ex, m in [0.5, 1)
+    int e = ex - 1;
+    int q = (int)std::nearbyint(std::ldexp(a, 3 - e));     // 8 .. 16
+    if (q == 16) { q = 8; ++e; }
+    const int code = ((e + 7) << 3) | (q - 8);
+    return sign | (uint8_t)(code > 0x7e ? 0x7e : code);
+}
+
+// rows of `cols` floats -> split fp16 (hi, lo) with leading dimension ld.  q8_exp != nullptr: `lo` receives the q8
+// image instead (xb_internal.h): per row and 32 columns [32 x e4m3(hi * 2^e) | 32 x e4m3(lo * 2^(e+11))], e chosen so
+// that the largest |value| lands near 224, and *q8_exp = e.
+void split_rows(const float *src, int rows, int cols, int ld, std::vector<half_t> &hi, std::vector<half_t> &lo,
+                int *q8_exp = nullptr)
 {
     hi.assign((size_t)rows * ld, (half_t)0.0f);
     lo.assign((size_t)rows * ld, (half_t)0.0f);
+    int e = 0;
+    if (q8_exp) {
+        float amax = 0.0f;
+        for (size_t i = 0; i < (size_t)rows * cols; ++i) amax = std::fmax(amax, std::fabs(src[i]));
+        if (amax > 0.0f && std::isfinite(amax)) e = (int)std::floor(std::log2(448.0f / amax)) - 1;
+        e = e < -16 ? -16 : (e > 32 ? 32 : e);
+        *q8_exp = e;
+    }
+    uint8_t *q = reinterpret_cast<uint8_t *>(lo.data());
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) {
             const float v = src[(size_t)r * cols + c];
             const half_t h = (half_t)v;
+            const float l = v - (float)h;
             hi[(size_t)r * ld + c] = h;
-            lo[(size_t)r * ld + c] = (half_t)(v - (float)h);
+            if (!q8_exp) {
+                lo[(size_t)r * ld + c] = (half_t)l;
+            } else {
+                uint8_t *blk = q + ((size_t)r * ld + (c & ~31)) * 2;
+                blk[c & 31] = f32_to_e4m3(std::ldexp((float)h, e));
+                blk[32 + (c & 31)] = f32_to_e4m3(std::ldexp(l, e + 11));
+            }
         }
 }
 
@@ -205,13 +246,14 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const ha
                    half_t *xout_lo)
 {
     const int F = ctx->cfg.features, T = ctx->T;
-    const int nsplit = ctx->cfg.precision == XB_PREC_F16 ? 1 : 3;
+    const int nsplit = ctx->cfg.precision == XB_PREC_F16 ? 1 : (ctx->cfg.precision == XB_PREC_F16F8 ? 2 : 3);
     {
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1);
         xb::GemmParams g{};
         g.a_hi = xin_hi; g.a_lo = xin_lo; g.b_hi = ctx->wih_hi[layer]; g.b_lo = ctx->wih_lo[layer];
         g.M = T * n; g.Nn = 4 * F; g.K = F; g.lda = F; g.ldb = F;
         g.bias = ctx->lbias[layer]; g.out_f32 = ctx->gin; g.ldc = 4 * F; g.nsplit = nsplit;
+        g.a_exp = layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[layer];     // conv3 output / LSTM output
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, ctx->stream));
     }
     const int members = xb::lstm_members(F), bn = xb::lstm_group_chunks();
@@ -224,7 +266,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const ha
     p.gin = ctx->gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
     p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state; p.xh = ctx->xh;
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
-    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = nsplit;
+    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = nsplit; p.w_exp = ctx->whh_exp[layer];
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
     if (mode == 2) {
         const int slab = gmax > 64 ? 64 * bn : gmax * bn;
@@ -253,18 +295,19 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
 {
     const xb_config &c = ctx->cfg;
     const int F = c.features, T = ctx->T;
-    const int nsplit = c.precision == XB_PREC_F16 ? 1 : 3;
+    const int nsplit = c.precision == XB_PREC_F16 ? 1 : (c.precision == XB_PREC_F16F8 ? 2 : 3);
     {
         StageScope sc(ctx, XB_STAGE_CONV, 2);
         xb::ConvFrontParams cf{};
         cf.signal = d_signal; cf.N = n; cf.L = c.chunk_len; cf.T = T; cf.winlen = c.winlen; cf.stride = c.stride;
         cf.kp = ctx->kp; cf.w1 = ctx->w1; cf.b1 = ctx->b1; cf.w2 = ctx->w2; cf.b2 = ctx->b2;
-        cf.a_hi = ctx->im_hi; cf.a_lo = ctx->im_lo;
+        cf.a_hi = ctx->im_hi; cf.a_lo = ctx->im_lo; cf.q8 = nsplit == 2;
         XB_HIP(ctx, xb::launch_conv_front(cf, ctx->stream));
         xb::GemmParams g{};
         g.a_hi = ctx->im_hi; g.a_lo = ctx->im_lo; g.b_hi = ctx->w3_hi; g.b_lo = ctx->w3_lo;
         g.M = T * n; g.Nn = F; g.K = ctx->kp; g.lda = ctx->kp; g.ldb = ctx->kp;
         g.bias = ctx->b3; g.out_hi = ctx->x_hi[0]; g.out_lo = ctx->x_lo[0]; g.ldc = F; g.nsplit = nsplit;
+        g.a_exp = 0; g.b_exp = ctx->w3_exp; g.out_exp = 0;
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_SILU_SPLIT, ctx->stream));
     }
     int cur = 0;
@@ -279,7 +322,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
         g.a_hi = ctx->x_hi[cur]; g.a_lo = ctx->x_lo[cur]; g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo;
         g.M = T * n; g.Nn = ctx->O; g.K = F; g.lda = F; g.ldb = F;
         g.bias = ctx->bl; g.out_f32 = scores_out; g.ldc = ldc; g.scale = c.scale; g.nb = c.n_base;
-        g.expand = expand; g.blank = c.blank_score; g.nsplit = nsplit;
+        g.expand = expand; g.blank = c.blank_score; g.nsplit = nsplit; g.a_exp = 8; g.b_exp = ctx->wl_exp;
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, ctx->stream));
     }
     return XB_OK;
@@ -342,7 +385,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (cfg->winlen < 1 || cfg->winlen > 31 || cfg->winlen % 2 == 0 || cfg->stride < 1 || cfg->stride > 8)
         return fail(nullptr, XB_ERR_INVALID, "winlen %d / stride %d unsupported", cfg->winlen, cfg->stride);
     if (cfg->chunk_len < cfg->stride || cfg->max_batch < 1) return fail(nullptr, XB_ERR_INVALID, "bad chunk_len/max_batch");
-    if (cfg->precision != XB_PREC_F16X3 && cfg->precision != XB_PREC_F16) return fail(nullptr, XB_ERR_INVALID, "bad precision");
+    if (cfg->precision != XB_PREC_F16X3 && cfg->precision != XB_PREC_F16 && cfg->precision != XB_PREC_F16F8) return fail(nullptr, XB_ERR_INVALID, "bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, XB_ERR_NO_GPU, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(nullptr, XB_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
@@ -463,7 +506,8 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
     if ((rc = upload(ctx, &ctx->b2, *need("encoder.1.conv.bias")))) return rc;
     if ((rc = upload(ctx, &ctx->b3, *need("encoder.2.conv.bias")))) return rc;
     std::vector<half_t> hi, lo;
-    split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo);
+    const bool q8 = ctx->cfg.precision == XB_PREC_F16F8;
+    split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo, q8 ? &ctx->w3_exp : nullptr);
     if ((rc = upload(ctx, &ctx->w3_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->w3_lo, lo))) return rc;
     for (int l = 0; l < 5; ++l) {
@@ -478,15 +522,15 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
                 memcpy(&wh[((size_t)u * 4 + q) * F], &whh[((size_t)q * F + u) * F], sizeof(float) * F);
                 bb[(size_t)u * 4 + q] = bih[(size_t)q * F + u] + bhh[(size_t)q * F + u];
             }
-        split_rows(wi.data(), 4 * F, F, F, hi, lo);
+        split_rows(wi.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->wih_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->wih_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->wih_lo[l], lo))) return rc;
-        split_rows(wh.data(), 4 * F, F, F, hi, lo);
+        split_rows(wh.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->whh_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->whh_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->whh_lo[l], lo))) return rc;
         if ((rc = upload(ctx, &ctx->lbias[l], bb))) return rc;
     }
-    split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo);
+    split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo, q8 ? &ctx->wl_exp : nullptr);
     if ((rc = upload(ctx, &ctx->wl_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->wl_lo, lo))) return rc;
     if ((rc = upload(ctx, &ctx->bl, *need("encoder.9.linear.bias")))) return rc;

@@ -39,6 +39,30 @@ __device__ __forceinline__ void split_f16(float v, half_t &hi, half_t &lo)
     lo = (half_t)(v - (float)hi);
 }
 
+// ---- q8 image helpers (xb_internal.h "q8 image"): OCP e4m3 bytes of hi * 2^e and of (v - hi) * 2^(e+11)
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float clamp448(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.0f), 448.0f); }
+// the conversion returns NaN (0x7f) above 448, hence the clamp wherever the magnitude is not bounded by construction
+template <bool HIGH_WORD>
+__device__ __forceinline__ unsigned fp8_pair(float a, float b, unsigned old)
+{
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HIGH_WORD);
+}
+__device__ __forceinline__ void q8_bytes(float v, int e, half_t &hi, unsigned char &h8, unsigned char &l8)
+{
+    hi = (half_t)v;
+    const float lo = v - (float)hi;
+    const unsigned pk = fp8_pair<false>(clamp448(__builtin_ldexpf((float)hi, e)), clamp448(__builtin_ldexpf(lo, e + 11)), 0u);
+    h8 = (unsigned char)(pk & 0xff);
+    l8 = (unsigned char)((pk >> 8) & 0xff);
+}
+// byte offset of element (row, col) inside a q8 image with `ld` columns: the h8 byte (its l8 byte is 32 further)
+__device__ __forceinline__ size_t q8_offset(size_t row, int ld, int col)
+{
+    return (row * ld + (size_t)(col & ~31)) * 2 + (col & 31);
+}
+
 // ======================================================================================
 // conv1 + conv2 + im2col of conv3's input
 // ======================================================================================
@@ -107,11 +131,21 @@ __global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
             const int c = col / W, k = col % W;
             v = a2[c * nq + tt * ST + k];
         }
-        half_t hi, lo;
-        split_f16(v, hi, lo);
-        const size_t o = ((size_t)t * p.N + n) * kp + col;
-        p.a_hi[o] = hi;
-        p.a_lo[o] = lo;
+        const size_t orow = (size_t)t * p.N + n;
+        if (p.q8) {
+            half_t hi;
+            unsigned char h8, l8;
+            q8_bytes(v, 0, hi, h8, l8);
+            unsigned char *q = reinterpret_cast<unsigned char *>(p.a_lo) + q8_offset(orow, kp, col);
+            p.a_hi[orow * kp + col] = hi;
+            q[0] = h8;
+            q[32] = l8;
+        } else {
+            half_t hi, lo;
+            split_f16(v, hi, lo);
+            p.a_hi[orow * kp + col] = hi;
+            p.a_lo[orow * kp + col] = lo;
+        }
     }
 }
 
@@ -170,10 +204,20 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
                 if (EPI == xb::EPI_BIAS_F32) {
                     p.out_f32[(size_t)m * p.ldc + n] = v;
                 } else if (EPI == xb::EPI_SILU_SPLIT) {
-                    half_t hi, lo;
-                    split_f16(silu(v), hi, lo);
-                    p.out_hi[(size_t)m * p.ldc + n] = hi;
-                    p.out_lo[(size_t)m * p.ldc + n] = lo;
+                    if (p.nsplit == 2) {
+                        half_t hi;
+                        unsigned char h8, l8;
+                        q8_bytes(silu(v), p.out_exp, hi, h8, l8);
+                        unsigned char *q = reinterpret_cast<unsigned char *>(p.out_lo) + q8_offset((size_t)m, p.ldc, n);
+                        p.out_hi[(size_t)m * p.ldc + n] = hi;
+                        q[0] = h8;
+                        q[32] = l8;
+                    } else {
+                        half_t hi, lo;
+                        split_f16(silu(v), hi, lo);
+                        p.out_hi[(size_t)m * p.ldc + n] = hi;
+                        p.out_lo[(size_t)m * p.ldc + n] = lo;
+                    }
                 } else {
                     p.out_f32[(size_t)m * p.ldc + ocol] = p.scale * fast_tanh(v);
                     if (p.expand && n % p.nb == 0) p.out_f32[(size_t)m * p.ldc + ocol - 1] = p.blank;
@@ -476,10 +520,12 @@ __global__ __launch_bounds__(GTHREADS) void gemm8_kernel(xb::GemmParams p)
 template <int EPI, int NSPLIT>
 __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 {
-    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    constexpr int NP = NSPLIT == 1 ? 1 : 2;     // operand parts: hi (+ lo, or + the q8 image when NSPLIT == 2)
     constexpr int PARTB = 128 * 64;            // one part (hi or lo) of a half-tile: 128 rows x 32 halves
     constexpr int HTB = NP * PARTB;            // half-tile bytes
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // [2 dbuf][4 half-tiles][HTB]
+    // [4 half-tiles][2 buffers][HTB]: the buffer index is the INNER dimension so that every fragment address of a wave is
+    // its one base register plus an immediate below 64 KiB (ds_read offsets are 16 bits)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
@@ -517,7 +563,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     } while (0)
 #define G8_WRITE(h, t)                                                                          \
     do {                                                                                        \
-        unsigned char *dst_ = ldst + ((((t) & 1) * 4 + (h)) * HTB);                             \
+        unsigned char *dst_ = ldst + (((h) * 2 + ((t) & 1)) * HTB);                             \
         *reinterpret_cast<u32x4 *>(dst_) = st[(h)][0];                                          \
         if (NP == 2) *reinterpret_cast<u32x4 *>(dst_ + PARTB) = st[(h)][1];                     \
     } while (0)
@@ -527,34 +573,75 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
         la[ks] = (unsigned)((lane & 31) * 64 + (((2 * ks + (lane >> 5)) ^ ((lane >> 2) & 3)) * 16));
-    const unsigned char *const fragA = smem_raw + wr * HTB;                                  // SA_wr
-    const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
+    const unsigned char *const fragA = smem_raw + wr * 2 * HTB;                              // SA_wr
+    const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * 2 * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
 
-    half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];     // A: [tile of the current M half][ks];  B: [n tile][ks]
+    // q8 image (NSPLIT == 2): a lane reads two cells of its row's 64-byte block -- A: lanes 0-31 the h8 half (cells 0, 1),
+    // lanes 32-63 the l8 half (cells 2, 3); B the other way round, so that the block-scaled MFMA (whose k index is a
+    // function of (lane half, byte) alone) pairs Ah8 with Bl8 and Al8 with Bh8.
+    unsigned lqa[2], lqb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int h = lane >> 5, sw = (lane >> 2) & 3;
+        lqa[j] = (unsigned)((lane & 31) * 64 + (((2 * h + j) ^ sw) * 16));
+        lqb[j] = (unsigned)((lane & 31) * 64 + (((2 * (1 - h) + j) ^ sw) * 16));
+    }
+    const int sca = 127 - p.a_exp - 11, scb = 127 - p.b_exp;      // E8M0 scale bytes: 2^-(a_exp + b_exp + 11) in all
+
+    // A: [tile of the current M half][ks]; B: [ks] of ONE n tile (B0 is read again for the last quadrant rather than kept:
+    // the LDS has the headroom, the register file has not)
+    half8 ah[2][2], al[2][2], bh[2], bl[2];
+    v8i aq[2], bq;                                    // NSPLIT == 2: q8 fragments (one 32-column block = the whole k-tile)
 #define G8_READ_A(d, mh)                                                                                  \
-    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {    \
-        const unsigned char *q_ = fragA + (d) * 4 * HTB + ((mh) * 2 + i2) * 2048 + la[ks];                \
-        ah[i2][ks] = *reinterpret_cast<const half8 *>(q_);                                                \
-        if (NP == 2) al[i2][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                           \
+    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) {                                                    \
+        const unsigned char *t_ = fragA + (d) * HTB + ((mh) * 2 + i2) * 2048;                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+            ah[i2][ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                   \
+            if (NSPLIT == 3) al[i2][ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + la[ks]);          \
+        }                                                                                                 \
+        if (NSPLIT == 2) {                                                                                \
+            const v4i x_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqa[0]);                           \
+            const v4i y_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqa[1]);                           \
+            aq[i2] = __builtin_shufflevector(x_, y_, 0, 1, 2, 3, 4, 5, 6, 7);                             \
+        }                                                                                                 \
     }
 #define G8_READ_B(d, n)                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
-        const unsigned char *q_ = fragB + (d) * 4 * HTB + (n) * 2048 + la[ks];                            \
-        bh[(n)][ks] = *reinterpret_cast<const half8 *>(q_);                                               \
-        if (NP == 2) bl[(n)][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                          \
-    }
+    do {                                                                                                  \
+        const unsigned char *t_ = fragB + (d) * HTB + (n) * 2048;                                     \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+            bh[ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                  \
+            if (NSPLIT == 3) bl[ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + la[ks]);         \
+        }                                                                                                 \
+        if (NSPLIT == 2) {                                                                                \
+            const v4i x_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqb[0]);                           \
+            const v4i y_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqb[1]);                           \
+            bq = __builtin_shufflevector(x_, y_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+        }                                                                                                 \
+    } while (0)
+#define G8_F16(i2, ks, n, A_, B_)                                                                         \
+    acc[(mh_) * 2 + (i2)][(n)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[(i2)][(ks)], B_[(ks)], acc[(mh_) * 2 + (i2)][(n)], 0, 0, 0)
 #define G8_MFMA(mh, n)                                                                                    \
     do {                                                                                                  \
+        constexpr int mh_ = (mh);                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-            if (NP == 2) {                                                                                \
-                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
-                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bl[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
+        if (NSPLIT == 2) {                                                                                \
+            G8_F16(0, 0, n, ah, bh);                                                                      \
+            G8_F16(1, 0, n, ah, bh);                                                                      \
+            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[mh_ * 2 + i2][(n)] =                     \
+                __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[i2], bq, acc[mh_ * 2 + i2][(n)], 0, 0, 0, sca, 0, scb); \
+            G8_F16(0, 1, n, ah, bh);                                                                      \
+            G8_F16(1, 1, n, ah, bh);                                                                      \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+                if (NSPLIT == 3) {                                                                        \
+                    G8_F16(0, ks, n, al, bh);                                                             \
+                    G8_F16(1, ks, n, al, bh);                                                             \
+                    G8_F16(0, ks, n, ah, bl);                                                             \
+                    G8_F16(1, ks, n, ah, bl);                                                             \
+                }                                                                                         \
+                G8_F16(0, ks, n, ah, bh);                                                                 \
+                G8_F16(1, ks, n, ah, bh);                                                                 \
             }                                                                                             \
-            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                    \
-                __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
         }                                                                                                 \
         __builtin_amdgcn_s_setprio(0);                                                                    \
     } while (0)
@@ -605,6 +692,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
         G8_BARRIER();                                                                       \
         G8_MFMA(1, 1);                                                                      \
         G8_BARRIER();                                                                       \
+        G8_READ_B(d, 0);                                                                    \
         G8_MOVE(3, t);                                                                      \
         G8_BARRIER();                                                                       \
         G8_MFMA(1, 0);                                                                      \
@@ -625,10 +713,14 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #undef G8_WRITE
 #undef G8_TILE
 #undef G8_MFMA
+#undef G8_F16
 #undef G8_READ_A
 #undef G8_READ_B
 
-    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);
+    // the epilogue's per-lane indices must not be computed (and kept in registers) ahead of the main loop
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane_e);
 }
 
 // ======================================================================================
@@ -693,7 +785,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     constexpr int KSP = KP / 16;                // MFMA k-steps per piece
     constexpr int CPR = KP / 8;                 // 16-byte cells per row per piece
     constexpr int SWZ = (CPR & -CPR) - 1;       // XOR mask that stays inside the row
-    constexpr int NPARTS = NSPLIT == 3 ? 2 : 1; // hi (, lo)
+    constexpr int NPARTS = NSPLIT == 1 ? 1 : 2; // hi (, lo or, NSPLIT == 2, the q8 image)
     constexpr int PIECE_BYTES = LG_BN * KP * 2; // one part of one piece
     static_assert(F % KP == 0, "feature size must be a multiple of the piece width");
 
@@ -721,7 +813,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     const int ubase = mb * LG_UNITS + wid * 8;   // first unit of this wave
 
     // ---- W_hh fragments: row = gate-interleaved (unit*4+gate), lane l: row (l&31), k-chunk (l>>5)
+    // NSPLIT == 2: per 32 columns one q8 fragment instead of two lo fragments -- lanes 0-31 hold the block's Wh8 half,
+    // lanes 32-63 its Wl8 half (A operand of the block-scaled MFMA; the h fragments below take the opposite halves)
     half8 wh[KS], wl[KS];
+    v8i wq[KS / 2 > 0 ? KS / 2 : 1];
     {
         const size_t row = (size_t)ubase * 4 + (lane & 31);
 #pragma unroll
@@ -729,7 +824,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             wh[k] = *reinterpret_cast<const half8 *>(p.w_hi + row * F + k * 16 + hsel * 8);
             if (NSPLIT == 3) wl[k] = *reinterpret_cast<const half8 *>(p.w_lo + row * F + k * 16 + hsel * 8);
         }
+        if (NSPLIT == 2) {
+            const unsigned char *wq8 = reinterpret_cast<const unsigned char *>(p.w_lo);
+#pragma unroll
+            for (int b = 0; b < KS / 2; ++b)
+                wq[b] = *reinterpret_cast<const v8i *>(wq8 + (row * F + b * 32) * 2 + hsel * 32);
+        }
     }
+    const int sca = 127 - p.w_exp, scb = 127 - 8 - 11;     // E8M0 scale bytes: W image exponent; h image exponent 8 (+11)
 
     // ---- cell state lives in LDS as [unit][chunk] (the register file is full of W_hh): lane owns
     //      (chunk = 32*nt + (l&31), unit = 8*wid + 2*rg + hsel), only ever touched by that lane
@@ -833,6 +935,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
                 // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use)
                 half8 fh[2][2], fl[2][2];
+                v8i fq[2];
                 auto load_frags = [&](int ks, half8 (&h)[2], half8 (&l)[2]) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
@@ -842,11 +945,25 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         if (NSPLIT == 3) l[nt] = *reinterpret_cast<const half8 *>(buf + PIECE_BYTES + (row * CPR + pos) * 16);
                     }
                 };
+                // q8 fragment of 32-column block `blk` of the piece: the half OPPOSITE to the W fragment's
+                // (lanes 0-31: the l8 cells 2, 3 of the block; lanes 32-63: the h8 cells 0, 1)
+                auto load_q8 = [&](int blk) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int row = nt * 32 + (lane & 31);
+                        const int c0 = 4 * blk + 2 * (1 - hsel);
+                        const unsigned char *rb = buf + PIECE_BYTES + row * CPR * 16;
+                        const v4i x = *reinterpret_cast<const v4i *>(rb + ((c0 ^ (row & SWZ)) * 16));
+                        const v4i y = *reinterpret_cast<const v4i *>(rb + (((c0 + 1) ^ (row & SWZ)) * 16));
+                        fq[nt] = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                };
                 load_frags(0, fh[0], fl[0]);
 #pragma unroll
                 for (int ks = 0; ks < KSP; ++ks) {
                     const int kg = pc * KSP + ks;
                     if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
+                    if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
@@ -855,6 +972,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fl[ks & 1][nt], acc[nt], 0, 0, 0);
                         }
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                    }
+                    if (NSPLIT == 2 && (ks & 1) == 1) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[kg >> 1], fq[nt], acc[nt], 0, 0, 0, sca, 0, scb);
                     }
                     // two per k-step so that the last one is issued by mid-piece and has landed at the barrier
                     if (pc + 1 < NP) {
@@ -876,6 +998,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             unsigned phi[4], plo[4];
+            float hq[4], lq[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
@@ -890,13 +1013,15 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 split_f16(hv, hi, lo);
                 phi[rg] = (unsigned)__builtin_bit_cast(unsigned short, hi);
                 plo[rg] = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                hq[rg] = (float)hi * 256.0f;                   // |h| < 1: below the e4m3 maximum by construction
+                lq[rg] = (hv - (float)hi) * 524288.0f;         // 2^19; |residual| <= 2^-11 |hi|
             }
             // lanes < 32 hold even units v[rg] = unit 2rg, lanes >= 32 the odd ones v[rg] = unit 2rg+1.
             // v_permlane32_swap(vdst, src) exchanges vdst's upper half-wave with src's lower half-wave, so
             //   swap(v[0], v[2]) -> {r[0], r[1]} = low lanes {unit 0, unit 1}, high lanes {unit 4, unit 5}
             //   swap(v[1], v[3]) -> low lanes {unit 2, unit 3}, high lanes {unit 6, unit 7}
 #pragma unroll
-            for (int part = 0; part < NPARTS; ++part) {
+            for (int part = 0; part < (NSPLIT == 3 ? 2 : 1); ++part) {
                 unsigned *v = part == 0 ? phi : plo;
                 auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
                 auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
@@ -906,6 +1031,20 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
                 dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
             }
+            if (NSPLIT == 2) {
+                // q8 image of the 32 units: 16 dword rows in the place of the lo staging -- rows 0..7 the h8 bytes of unit
+                // quads 0..7, rows 8..15 their l8 bytes, so the 16-byte cell reads below need no change.
+                // X = {h8(u_a), h8(u_b), l8(u_a), l8(u_b)} of this lane's units (rg 0, 1), Y of (rg 2, 3); after the swap
+                // low lanes hold units (0,2) / (1,3), high lanes (4,6) / (5,7): one byte permute per image interleaves them.
+                unsigned X = fp8_pair<false>(hq[0], hq[1], 0u), Y = fp8_pair<false>(hq[2], hq[3], 0u);
+                X = fp8_pair<true>(lq[0], lq[1], X);
+                Y = fp8_pair<true>(lq[2], lq[3], Y);
+                auto r = __builtin_amdgcn_permlane32_swap(X, Y, false, false);
+                const unsigned r0 = r[0], r1 = r[1];
+                unsigned *dst = sT + 16 * ST_LD + nt * 32 + (lane & 31);
+                dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+                dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+            }
         }
         __syncthreads();
         // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part (cell = 4 unit pairs of one chunk)
@@ -914,7 +1053,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         {
             const unsigned *src = sT + (occ * 4) * ST_LD + orow;
             vhi = make_uint4(src[0], src[ST_LD], src[2 * ST_LD], src[3 * ST_LD]);
-            if (NSPLIT == 3) {
+            if (NSPLIT != 1) {
                 const unsigned *sl = src + 16 * ST_LD;
                 vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
             }
@@ -924,7 +1063,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             // publish h_t for the group (rows beyond the slab are scratch rows of the exchange buffer)
             half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
             store16_sc1(xcur, vhi);
-            if (NSPLIT == 3) store16_sc1(xcur + XPART, vlo);
+            if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
         }
         XB_STAMP(4);   // pointwise + exchange stores issued
         if (p.persistent && s + 1 < p.s_end) {
@@ -964,7 +1103,7 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 {
     constexpr int F = KS * 16;
     constexpr int KP = F < 128 ? F : 128;
-    const int nparts = p.nsplit == 3 ? 2 : 1;
+    const int nparts = p.nsplit == 1 ? 1 : 2;
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const int g8 = (ngroups + 7) & ~7;
     const int members = F / LG_UNITS;
@@ -973,6 +1112,8 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     dim3 grid(g8 * members), block(256);
     if (p.nsplit == 3)
         hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
+    else if (p.nsplit == 2)
+        hipLaunchKernelGGL((lstm_kernel<KS, 2>), grid, block, lds, stream, p);
     else
         hipLaunchKernelGGL((lstm_kernel<KS, 1>), grid, block, lds, stream, p);
     return hipGetLastError();
@@ -985,11 +1126,17 @@ hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
     const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
     const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see the tile order in gemm_kernel
     dim3 grid(8 * 32 * ((supers + 7) / 8)), block(GTHREADS);
-    const size_t lds = (size_t)2 * (p.nsplit == 3 ? 4 : 2) * GBM * 4 * sizeof(uint4);
+    const size_t lds = (size_t)2 * (p.nsplit != 1 ? 4 : 2) * GBM * 4 * sizeof(uint4);
     static const int variant = [] {                 // XB_GEMM_KERNEL=1: the register-staged kernel (A/B runs)
         const char *e = getenv("XB_GEMM_KERNEL");
         return e ? atoi(e) : 8;
     }();
+    if (p.nsplit == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm8r_kernel<EPI, 2>), grid, block, lds, stream, p);
+        return hipGetLastError();
+    }
     if (variant == 8) {
         if (p.nsplit == 3) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 3>),
@@ -1046,7 +1193,7 @@ hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream)
     if (p.M < 1 || p.Nn < 1 || p.K < GBK || p.K % GBK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 ||
         p.lda < p.K || p.ldb < p.K)
         return hipErrorInvalidValue;
-    if (p.nsplit != 1 && p.nsplit != 3) return hipErrorInvalidValue;
+    if (p.nsplit < 1 || p.nsplit > 3) return hipErrorInvalidValue;
     switch (epilogue) {
     case EPI_BIAS_F32: return launch_gemm_epi<EPI_BIAS_F32>(p, stream);
     case EPI_SILU_SPLIT: return launch_gemm_epi<EPI_SILU_SPLIT>(p, stream);
@@ -1081,7 +1228,7 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (!lstm_supported_features(p.F) || p.nslab < 1 || p.s_begin < 0 || p.s_end > p.T || p.s_begin >= p.s_end)
         return hipErrorInvalidValue;
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
-    if (p.nsplit != 1 && p.nsplit != 3) return hipErrorInvalidValue;
+    if (p.nsplit < 1 || p.nsplit > 3) return hipErrorInvalidValue;
     switch (p.F / 16) {
     case 2: return launch_lstm_ks<2>(p, stream);
     case 4: return launch_lstm_ks<4>(p, stream);

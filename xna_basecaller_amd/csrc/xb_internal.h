@@ -35,13 +35,20 @@ struct ConvFrontParams {
     int N, L, T, winlen, stride, kp;
     const float *w1, *b1;  // (4,1,5), (4)
     const float *w2, *b2;  // (16,4,5), (16)
-    half_t *a_hi, *a_lo;   // (T*N, kp)
+    half_t *a_hi, *a_lo;   // (T*N, kp); a_lo holds the q8 image instead when q8 != 0
+    int q8;                // 1: second part = fp8 image (see "q8 image" below), activation exponent 0
 };
 hipError_t launch_conv_front(const ConvFrontParams &p, hipStream_t stream);
 
 enum GemmEpilogue { EPI_BIAS_F32 = 0, EPI_SILU_SPLIT = 1, EPI_TANH_SCALE = 2 };
 
-// D[m][n] = sum_k A[m][k] * B[n][k]  (+ epilogue); A, B split fp16 (hi, lo), K multiple of 32.
+// q8 image (precision XB_PREC_F16F8): the second part of every operand is not the fp16 residual but, byte for byte in
+// its place, per row and per 32 columns a 64-byte block [h8: 32 x e4m3 of hi * 2^e | l8: 32 x e4m3 of lo * 2^(e+11)]
+// (e = the tensor's exponent: 8 for LSTM outputs |h| < 1, 0 for the conv tensors, chosen per weight tensor from max|W|).
+// One block-scaled MFMA (K = 64) then computes BOTH correction products of 32 columns: lanes 0-31 feed Ah8 x Bl8,
+// lanes 32-63 feed Al8 x Bh8, both with the scale 2^-(ea + eb + 11).
+
+// D[m][n] = sum_k A[m][k] * B[n][k]  (+ epilogue); A, B split fp16 (hi, lo / q8), K multiple of 32.
 struct GemmParams {
     const half_t *a_hi, *a_lo;   // (M, lda)
     const half_t *b_hi, *b_lo;   // (Nn, ldb)
@@ -53,7 +60,9 @@ struct GemmParams {
     float scale;                 // EPI_TANH_SCALE
     int nb, expand;              // EPI_TANH_SCALE : insert blank column in front of every nb outputs
     float blank;
-    int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only
+    int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only ; 2 = hi*hi + fp8 corrections (q8 images)
+    int a_exp, b_exp;            // nsplit == 2: exponents of the A and B q8 images
+    int out_exp;                 // nsplit == 2, EPI_SILU_SPLIT: exponent of the q8 image written to out_lo
 };
 hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream);
 
@@ -73,7 +82,8 @@ struct LstmParams {
     int persistent;              // 1: all steps in one launch with inter-workgroup sync
     unsigned *sync;              // per-group arrival counters (zeroed before a persistent launch), stride 32 words
     unsigned *error;             // set non-zero when a sync wait timed out
-    int nsplit;
+    int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8)
+    int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
