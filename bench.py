@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--nbase", type=int, default=5, choices=[4, 5, 6])
     ap.add_argument("--features", type=int, default=768)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16", "f16f8"])
+    ap.add_argument("--precision", default="f16f8", choices=["f16x3", "f16", "f16f8"])
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--lstm-mode", type=int, default=0)
     args = ap.parse_args()

@@ -27,7 +27,7 @@ def test_model_forward_and_decode_batch():
     scores = model(x)
     assert scores.shape == (200, 4, 1512)
     ref = oracle.encode(x, sd, 64, 6, 3)
-    assert np.abs(scores - ref).max() < 1e-4
+    assert np.abs(scores - ref).max() < 2e-4
     # decode the GPU's own scores with both implementations: identical strings
     assert model.decode_batch(scores) == oracle.decode_batch(scores, list("NACGTXY"), 3)
 

@@ -141,8 +141,10 @@ class Model(torch.nn.Module):
         self._device = 0
         self._ctx = None
         self._ctx_key = None
-        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16}[
-            os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "f16x3"))]
+        # f16f8 (default): fp16 product + FP8 block-scaled correction products, |score error| ~4e-5; f16x3: three fp16
+        # products, ~3e-6; f16: one product, ~1e-3 (what the reference's model.half() computes)
+        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8}[
+            os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "f16f8"))]
 
     # ---- torch.nn.Module surface used by load_model -------------------------------------
     def to(self, device=None, *args, **kwargs):

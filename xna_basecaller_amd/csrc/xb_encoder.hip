@@ -182,18 +182,39 @@ __device__ __forceinline__ bool gemm_tile_origin(const xb::GemmParams &p, int &m
 }
 
 // epilogue shared by the GEMM kernels: a wave holds 4 x 2 accumulator tiles of 32x32 (rows wm*128.., cols wn*64..);
-// a lane holds column (lane & 31) and 16 rows of each tile
+// a lane holds column (lane & 31) and 16 rows of each tile.  The bias is loaded ONCE, ahead of all stores: a load inside the
+// store loop makes every store wait (vmcnt counts stores too) for the one before it.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const floatx16 (&acc)[4][2], int m0, int n0,
                                               int wm, int wn, int lane)
 {
+    float bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        bj[j] = (p.bias && n < p.Nn) ? p.bias[n] : 0.0f;
+    }
+    if (EPI == xb::EPI_BIAS_F32 && m0 + GBM <= p.M && n0 + GBN <= p.Nn) {
+        // interior tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset
+        float *tile = p.out_f32 + (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);
+        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rowp[loff + j * 32] = acc[i][j][r] + bj[j];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
             if (n >= p.Nn) continue;
-            const float bias = p.bias ? p.bias[n] : 0.0f;
+            const float bias = bj[j];
             int ocol = n;
             if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
 #pragma unroll
@@ -594,6 +615,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     v8i aq[2], bq;                                    // NSPLIT == 2: q8 fragments (one 32-column block = the whole k-tile)
 #define G8_READ_A(d, mh)                                                                                  \
     _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) {                                                    \
+        if (G8_DBG(4)) break;                                                                             \
         const unsigned char *t_ = fragA + (d) * HTB + ((mh) * 2 + i2) * 2048;                         \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
             ah[i2][ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                   \
@@ -607,6 +629,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     }
 #define G8_READ_B(d, n)                                                                                   \
     do {                                                                                                  \
+        if (G8_DBG(4)) break;                                                                             \
         const unsigned char *t_ = fragB + (d) * HTB + (n) * 2048;                                     \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
             bh[ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                  \
@@ -623,6 +646,7 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #define G8_MFMA(mh, n)                                                                                    \
     do {                                                                                                  \
         constexpr int mh_ = (mh);                                                                         \
+        if (G8_DBG(1)) break;                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                    \
         if (NSPLIT == 2) {                                                                                \
             G8_F16(0, 0, n, ah, bh);                                                                      \
@@ -667,8 +691,14 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 
     // phase (t, q): fragment reads of quadrant q; write half-tile q of tile t+1 into the other buffer (its last reads were
     // in tile t-1); reload the staging registers with half-tile q of tile t+2; retire the LDS operations; barrier.
+#ifdef XB_LSTM_STAMPS
+#define G8_DBG(bit) (p.dbg & (bit))
+#else
+#define G8_DBG(bit) 0
+#endif
 #define G8_MOVE(q, t)                                                                       \
     do {                                                                                    \
+        if (G8_DBG(2)) break;                                                               \
         G8_WRITE(q, (t) + 1);                                                               \
         __builtin_amdgcn_sched_barrier(0);      /* reload the SAME registers after the write */ \
         G8_LOAD(q, (t) + 2 < nk ? (t) + 2 : nk - 1);                                        \
@@ -1131,6 +1161,9 @@ hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
         const char *e = getenv("XB_GEMM_KERNEL");
         return e ? atoi(e) : 8;
     }();
+#ifdef XB_LSTM_STAMPS
+    if (const char *e = getenv("XB_GEMM_DBG")) const_cast<xb::GemmParams &>(p).dbg = atoi(e);
+#endif
     if (p.nsplit == 2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
