@@ -207,7 +207,6 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin, ldq = p.ldq;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x;
     const int st = tid / LPS, ph = tid % LPS;    // state and position inside its lane cluster
     const bool act = st < S;

@@ -121,31 +121,51 @@ __global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
         a2[c * nq + r] = v;
     }
     __syncthreads();
-    const int kp = p.kp, kv = 16 * W;
-    for (int i = tid; i < CF_TT * kp; i += 256) {
-        const int tt = i / kp, col = i % kp;
+    // im2col rows of this tile, four consecutive columns per thread: 8 bytes of hi and either 8 bytes of lo or, for the
+    // q8 image, one dword of h8 and one of l8 (four columns never straddle a 32-column block)
+    const int kp = p.kp, kv = 16 * W, kq = kp / 4;
+    for (int i = tid; i < CF_TT * kq; i += 256) {
+        const int tt = i / kq, col = (i % kq) * 4;
         const int t = t0 + tt;
         if (t >= p.T) break;
-        float v = 0.0f;
-        if (col < kv) {
-            const int c = col / W, k = col % W;
-            v = a2[c * nq + tt * ST + k];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = col + j;
+            v[j] = cj < kv ? a2[(cj / W) * nq + tt * ST + cj % W] : 0.0f;
         }
         const size_t orow = (size_t)t * p.N + n;
+        half_t hi[4];
+        unsigned short hb[4];
         if (p.q8) {
-            half_t hi;
-            unsigned char h8, l8;
-            q8_bytes(v, 0, hi, h8, l8);
+            float lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = (half_t)v[j];
+                lo[j] = clamp448((v[j] - (float)hi[j]) * 2048.0f);      // exponent 0: l8 = lo * 2^11
+                hb[j] = __builtin_bit_cast(unsigned short, hi[j]);
+            }
+            unsigned h8 = fp8_pair<false>(clamp448((float)hi[0]), clamp448((float)hi[1]), 0u);
+            h8 = fp8_pair<true>(clamp448((float)hi[2]), clamp448((float)hi[3]), h8);
+            unsigned l8 = fp8_pair<false>(lo[0], lo[1], 0u);
+            l8 = fp8_pair<true>(lo[2], lo[3], l8);
             unsigned char *q = reinterpret_cast<unsigned char *>(p.a_lo) + q8_offset(orow, kp, col);
-            p.a_hi[orow * kp + col] = hi;
-            q[0] = h8;
-            q[32] = l8;
+            *reinterpret_cast<unsigned *>(q) = h8;
+            *reinterpret_cast<unsigned *>(q + 32) = l8;
         } else {
-            half_t hi, lo;
-            split_f16(v, hi, lo);
-            p.a_hi[orow * kp + col] = hi;
-            p.a_lo[orow * kp + col] = lo;
+            unsigned short lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half_t lo;
+                split_f16(v[j], hi[j], lo);
+                hb[j] = __builtin_bit_cast(unsigned short, hi[j]);
+                lb[j] = __builtin_bit_cast(unsigned short, lo);
+            }
+            *reinterpret_cast<uint2 *>(p.a_lo + orow * kp + col) =
+                make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
         }
+        *reinterpret_cast<uint2 *>(p.a_hi + orow * kp + col) =
+            make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
     }
 }
 
@@ -208,6 +228,38 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
             }
         return;
     }
+    if (EPI == xb::EPI_SILU_SPLIT && m0 + GBM <= p.M && n0 + GBN <= p.Nn) {
+        // interior tile of the conv3 GEMM: hi as fp16, second part as fp16 residual or q8 bytes; no bounds checks
+        const size_t tile = (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);       // element offset of the wave's tile
+        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+        unsigned char *q8base = reinterpret_cast<unsigned char *>(p.out_lo) + tile * 2;    // n0 + wn*64 is a multiple of 32
+        const int qoff = (4 * (lane >> 5)) * p.ldc * 2 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t ro = (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = silu(acc[i][j][r] + bj[j]);
+                    if (p.nsplit == 2) {
+                        half_t hi;
+                        unsigned char h8, l8;
+                        q8_bytes(v, p.out_exp, hi, h8, l8);
+                        p.out_hi[tile + ro + loff + j * 32] = hi;
+                        unsigned char *q = q8base + ro * 2 + qoff + j * 64;
+                        q[0] = h8;
+                        q[32] = l8;
+                    } else {
+                        half_t hi, lo;
+                        split_f16(v, hi, lo);
+                        p.out_hi[tile + ro + loff + j * 32] = hi;
+                        p.out_lo[tile + ro + loff + j * 32] = lo;
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -247,296 +299,31 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
         }
 }
 
-struct Stage2 { uint4 v[2]; };
-
-// 256 rows x 32 halves of one operand part = 1024 cells of 16 B; thread `tid` moves cells tid, tid+512
-__device__ __forceinline__ Stage2 load_part(int tid, int kt, const half_t *base, int ldp, int row0, int rlast)
-{
-    Stage2 s;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + GTHREADS * i, row = c >> 2, kc = c & 3;
-        int rg = row0 + row;
-        rg = rg > rlast ? rlast : rg;
-        s.v[i] = *reinterpret_cast<const uint4 *>(base + (size_t)rg * ldp + kt * GBK + kc * 8);
-    }
-    return s;
-}
-__device__ __forceinline__ void write_part(int tid, uint4 *part, const Stage2 &s)
-{
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + GTHREADS * i, row = c >> 2, kc = c & 3;
-        part[row * 4 + (kc ^ ((row >> 2) & 3))] = s.v[i];
-    }
-}
-
-template <int EPI, int NSPLIT>
-__global__ __launch_bounds__(GTHREADS, 2) void gemm_kernel(xb::GemmParams p)
-{
-    constexpr int NPART = NSPLIT == 3 ? 4 : 2;               // Ahi,(Alo),Bhi,(Blo)
-    constexpr int PA_LO = 1, PB_HI = NSPLIT == 3 ? 2 : 1, PB_LO = 3;
-    constexpr int WM = 4, WN = 2;                             // 32x32 tiles per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint4(*lds)[NPART][GBM * 4] = reinterpret_cast<uint4(*)[NPART][GBM * 4]>(smem_raw);   // [2][NPART][1024]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    int m0, n0;
-    if (!gemm_tile_origin(p, m0, n0)) return;
-    const int nk = p.K / GBK;
-
-    Stage2 sAh, sAl, sBh, sBl;
-    const int Mlast = p.M - 1, Nlast = p.Nn - 1;
-#define XB_LOAD_REGS(kt)                                                              \
-    do {                                                                              \
-        sAh = load_part(tid, (kt), p.a_hi, p.lda, m0, Mlast);                         \
-        sBh = load_part(tid, (kt), p.b_hi, p.ldb, n0, Nlast);                         \
-        if (NSPLIT == 3) {                                                            \
-            sAl = load_part(tid, (kt), p.a_lo, p.lda, m0, Mlast);                     \
-            sBl = load_part(tid, (kt), p.b_lo, p.ldb, n0, Nlast);                     \
-        }                                                                             \
-    } while (0)
-#define XB_WRITE_LDS(st)                                                              \
-    do {                                                                              \
-        write_part(tid, lds[(st)][0], sAh);                                           \
-        write_part(tid, lds[(st)][PB_HI], sBh);                                       \
-        if (NSPLIT == 3) {                                                            \
-            write_part(tid, lds[(st)][PA_LO], sAl);                                   \
-            write_part(tid, lds[(st)][PB_LO], sBl);                                   \
-        }                                                                             \
-    } while (0)
-    auto frag = [&](int st, int q, int rb, int s) -> half8 {
-        const int row = rb * 32 + (lane & 31), kc = 2 * s + (lane >> 5);
-        const uint4 v = lds[st][q][row * 4 + (kc ^ ((row >> 2) & 3))];
-        return __builtin_bit_cast(half8, v);
-    };
-
-    floatx16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // pipeline: LDS holds tile kt, the staging registers hold tile kt+1 (written to the other stage at the START
-    // of iteration kt, so the ds_writes overlap other waves' MFMAs), global loads of tile kt+2 are in flight.
-    XB_LOAD_REGS(0);
-    XB_WRITE_LDS(0);
-    if (nk > 1) XB_LOAD_REGS(1);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nk) XB_WRITE_LDS(st ^ 1);
-        if (kt + 2 < nk) XB_LOAD_REGS(kt + 2);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            half8 bh[WN], bl[WN];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                bh[j] = frag(st, PB_HI, WN * wn + j, s);
-                if (NSPLIT == 3) bl[j] = frag(st, PB_LO, WN * wn + j, s);
-            }
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const half8 ah = frag(st, 0, WM * wm + i, s);
-                half8 al;
-                if (NSPLIT == 3) al = frag(st, PA_LO, WM * wm + i, s);
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    if (NSPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-#undef XB_LOAD_REGS
-#undef XB_WRITE_LDS
-
-    gemm_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
-}
-
 // ======================================================================================
-// gemm8_kernel: the same 256x256x32 split-fp16 tile, scheduled as a two-group ping-pong
-// (cdna_hip_programming.md "256^2 8-phase template", adapted to 4-byte hi+lo elements).
-//  * Operand tiles are staged by LDS-DMA in four 16-KiB half-tiles per k-tile (SA0, SA1 = block rows 0..127 /
-//    128..255 of A; SB0, SB1 likewise for B), two 1-KiB pieces (hi, lo) per wave and half-tile, source cells
-//    pre-swizzled so the LDS image is the XOR-swizzled one the fragment reads expect.  No staging registers.
-//  * A k-tile is four phases, one 64x32 output quadrant of the wave each (12 MFMAs = 2 M-tiles x 2 k-steps x 3
-//    products):  q0 (A0,B0)  q1 (A0,B1)  q2 (A1,B1)  q3 (A1,B0).  Phase = {fragment reads + DMA issue} barrier
-//    {MFMAs} barrier.  Waves 4-7 (wr = 1) run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA
-//    cluster while the other reads LDS / issues DMA.
-//  * DMA order per tile t:  q0: SA1(t+1)   q2: SB0(t+2), SB1(t+2)   q3: SA0(t+2), then ONE counted wait
-//    (vmcnt = the 6 pieces issued after SA1(t+1)) before q3's first barrier; tile t+1 is first read two barriers later.
-//    Re-staging rules (WAR): a half-tile slot is re-staged two phases after its last fragment read, or one phase after
-//    when that read phase retires its reads (lgkmcnt(0)) before its first barrier (q1 for SB, q2 for SA).
+// split-fp16 MFMA GEMM:  D[m][n] = sum_k A[m][k] B[n][k]   (gemm8r_kernel)
+// 256x256 block tile, BK = 32, 8 waves (2 in M x 4 in N), each wave 128x64 = 4x2 MFMA 32x32 tiles.
+// Products per tile pair and k-tile: NSPLIT 3: six fp16 MFMAs (lo*hi, hi*lo, hi*hi per 16-deep k-step);
+// NSPLIT 2: two fp16 MFMAs + ONE block-scaled FP8 MFMA (K = 64) for both correction products (q8 images);
+// NSPLIT 1: two fp16 MFMAs.
+//  * LDS image per half-tile part: [128 rows][4 cells of 16 B], cell index XOR-swizzled with (row >> 2) & 3 so that every
+//    16-lane ds_read_b128 group hits 16 distinct bank slots (SQ_LDS_BANK_CONFLICT = 0).
+//  * Operand tiles are staged in four 16-KiB half-tiles per k-tile (SA0, SA1 = block rows 0..127 / 128..255 of A; SB0, SB1
+//    likewise for B) through 32 staging registers per lane: loaded from global memory one tile ahead, written to the
+//    other LDS buffer a tile later (three half-tiles always in flight; the tile body is branch-free so that the compiler's
+//    own vmcnt bookkeeping stays exact).  LDS-DMA staging was measured at the same speed (its issue cost inside a
+//    phase that also carries the fragment reads is 100+ cycles per piece) and dropped.
+//  * A k-tile is four phases, one 64x32 output quadrant of the wave each:  q0 (A0,B0)  q1 (A0,B1)  q2 (A1,B1)  q3 (A1,B0).
+//    Phase = {fragment reads + staging moves} barrier {MFMA cluster} barrier.  Waves 4-7 (wr = 1) run one barrier behind
+//    waves 0-3, so on every SIMD one wave is in its MFMA cluster while the other reads LDS / moves staging data
+//    (cdna_hip_programming.md "256^2 8-phase template", adapted to 4-byte elements).
+//  * Workgroup -> tile order is XCD-aware (gemm_tile_origin), the epilogue stores interior tiles branch-free.
 // ======================================================================================
-__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
 #define G8_BARRIER()                                   \
     do {                                               \
         __builtin_amdgcn_sched_barrier(0);             \
         __builtin_amdgcn_s_barrier();                  \
         __builtin_amdgcn_sched_barrier(0);             \
     } while (0)
-
-template <int EPI, int NSPLIT>
-__global__ __launch_bounds__(GTHREADS) void gemm8_kernel(xb::GemmParams p)
-{
-    constexpr int NP = NSPLIT == 3 ? 2 : 1;
-    constexpr int PARTB = 128 * 64;            // one part (hi or lo) of a half-tile: 128 rows x 32 halves
-    constexpr int HTB = NP * PARTB;            // half-tile bytes
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // [2 dbuf][4 half-tiles][HTB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
-    int m0, n0;
-    if (!gemm_tile_origin(p, m0, n0)) return;
-    const int nk = p.K / GBK;
-    const half_t *a_hi = p.a_hi, *a_lo = p.a_lo, *b_hi = p.b_hi, *b_lo = p.b_lo;
-
-    // ---- DMA source offsets (elements): lane i of wave w fills slot i of rows 16w..16w+15 of a half-tile part:
-    //      row 16w + (i >> 2), LDS cell (i & 3) <- source cell (i & 3) ^ ((row >> 2) & 3)
-    size_t offs[4];
-    {
-        const int drow = 16 * wid + (lane >> 2), dch = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-        const int Mlast = p.M - 1, Nlast = p.Nn - 1;
-        int r;
-        r = m0 + drow;        offs[0] = (size_t)(r > Mlast ? Mlast : r) * p.lda + dch;
-        r = m0 + 128 + drow;  offs[1] = (size_t)(r > Mlast ? Mlast : r) * p.lda + dch;
-        r = n0 + drow;        offs[2] = (size_t)(r > Nlast ? Nlast : r) * p.ldb + dch;
-        r = n0 + 128 + drow;  offs[3] = (size_t)(r > Nlast ? Nlast : r) * p.ldb + dch;
-    }
-    unsigned char *const wdst = smem_raw + wid * 1024;
-#define G8_STAGE(h, t)                                                                          \
-    do {                                                                                        \
-        unsigned char *dst_ = wdst + ((((t) & 1) * 4 + (h)) * HTB);                             \
-        const size_t o_ = offs[(h)] + (size_t)(t) * GBK;                                        \
-        dma16(((h) < 2 ? a_hi : b_hi) + o_, dst_);                                              \
-        if (NP == 2) dma16(((h) < 2 ? a_lo : b_lo) + o_, dst_ + PARTB);                         \
-    } while (0)
-
-    // ---- fragment read offsets (bytes): row (lane & 31) of a 32-row tile, cell (2 ks + (lane >> 5)) ^ ((row >> 2) & 3)
-    unsigned la[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-        la[ks] = (unsigned)((lane & 31) * 64 + (((2 * ks + (lane >> 5)) ^ ((lane >> 2) & 3)) * 16));
-    const unsigned char *const fragA = smem_raw + wr * HTB;                                  // SA_wr
-    const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
-
-    half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];     // A: [tile of the current M half][ks];  B: [n tile][ks]
-#define G8_READ_A(d, mh)                                                                                  \
-    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {    \
-        const unsigned char *q_ = fragA + (d) * 4 * HTB + ((mh) * 2 + i2) * 2048 + la[ks];                \
-        ah[i2][ks] = *reinterpret_cast<const half8 *>(q_);                                                \
-        if (NP == 2) al[i2][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                           \
-    }
-#define G8_READ_B(d, n)                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
-        const unsigned char *q_ = fragB + (d) * 4 * HTB + (n) * 2048 + la[ks];                            \
-        bh[(n)][ks] = *reinterpret_cast<const half8 *>(q_);                                               \
-        if (NP == 2) bl[(n)][ks] = *reinterpret_cast<const half8 *>(q_ + PARTB);                          \
-    }
-#define G8_MFMA(mh, n)                                                                                    \
-    do {                                                                                                  \
-        __builtin_amdgcn_s_setprio(1);                                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-            if (NP == 2) {                                                                                \
-                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
-                _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bl[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
-            }                                                                                             \
-            _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[(mh) * 2 + i2][(n)] =                    \
-                __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i2][ks], bh[(n)][ks], acc[(mh) * 2 + i2][(n)], 0, 0, 0); \
-        }                                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                    \
-    } while (0)
-
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // ---- prologue: tile 0 complete; SB0(1), SB1(1), SA0(1) in flight
-    G8_STAGE(0, 0);
-    G8_STAGE(1, 0);
-    G8_STAGE(2, 0);
-    G8_STAGE(3, 0);
-    if (nk > 1) {
-        G8_STAGE(2, 1);
-        G8_STAGE(3, 1);
-        G8_STAGE(0, 1);
-        if (NP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    G8_BARRIER();
-    if (wr == 1) G8_BARRIER();          // the second wave group runs one barrier behind the first
-
-#define G8_TILE(d, t)                                                                       \
-    do {                                                                                    \
-        /* q0 */                                                                            \
-        G8_READ_B(d, 0);                                                                    \
-        G8_READ_A(d, 0);                                                                    \
-        if ((t) + 1 < nk) G8_STAGE(1, (t) + 1);                                             \
-        G8_BARRIER();                                                                       \
-        G8_MFMA(0, 0);                                                                      \
-        G8_BARRIER();                                                                       \
-        /* q1 */                                                                            \
-        G8_READ_B(d, 1);                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
-        G8_BARRIER();                                                                       \
-        G8_MFMA(0, 1);                                                                      \
-        G8_BARRIER();                                                                       \
-        /* q2 */                                                                            \
-        G8_READ_A(d, 1);                                                                    \
-        if ((t) + 2 < nk) {                                                                 \
-            G8_STAGE(2, (t) + 2);                                                           \
-            G8_STAGE(3, (t) + 2);                                                           \
-        }                                                                                   \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
-        G8_BARRIER();                                                                       \
-        G8_MFMA(1, 1);                                                                      \
-        G8_BARRIER();                                                                       \
-        /* q3 */                                                                            \
-        if ((t) + 2 < nk) {                                                                 \
-            G8_STAGE(0, (t) + 2);                                                           \
-            if (NP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   \
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
-        } else {                                                                            \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-        }                                                                                   \
-        G8_BARRIER();                                                                       \
-        G8_MFMA(1, 0);                                                                      \
-        G8_BARRIER();                                                                       \
-    } while (0)
-
-    for (int t = 0; t < nk; t += 2) {
-        G8_TILE(0, t);
-        if (t + 1 < nk) G8_TILE(1, t + 1);
-    }
-    if (wr == 0) G8_BARRIER();          // matches the extra barrier of the second group
-#undef G8_TILE
-#undef G8_MFMA
-#undef G8_READ_A
-#undef G8_READ_B
-#undef G8_STAGE
-
-    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane);
-}
 
 template <int EPI, int NSPLIT>
 __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
@@ -615,7 +402,6 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     v8i aq[2], bq;                                    // NSPLIT == 2: q8 fragments (one 32-column block = the whole k-tile)
 #define G8_READ_A(d, mh)                                                                                  \
     _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) {                                                    \
-        if (G8_DBG(4)) break;                                                                             \
         const unsigned char *t_ = fragA + (d) * HTB + ((mh) * 2 + i2) * 2048;                         \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
             ah[i2][ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                   \
@@ -629,7 +415,6 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     }
 #define G8_READ_B(d, n)                                                                                   \
     do {                                                                                                  \
-        if (G8_DBG(4)) break;                                                                             \
         const unsigned char *t_ = fragB + (d) * HTB + (n) * 2048;                                     \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
             bh[ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                  \
@@ -646,7 +431,6 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #define G8_MFMA(mh, n)                                                                                    \
     do {                                                                                                  \
         constexpr int mh_ = (mh);                                                                         \
-        if (G8_DBG(1)) break;                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                    \
         if (NSPLIT == 2) {                                                                                \
             G8_F16(0, 0, n, ah, bh);                                                                      \
@@ -691,14 +475,8 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 
     // phase (t, q): fragment reads of quadrant q; write half-tile q of tile t+1 into the other buffer (its last reads were
     // in tile t-1); reload the staging registers with half-tile q of tile t+2; retire the LDS operations; barrier.
-#ifdef XB_LSTM_STAMPS
-#define G8_DBG(bit) (p.dbg & (bit))
-#else
-#define G8_DBG(bit) 0
-#endif
 #define G8_MOVE(q, t)                                                                       \
     do {                                                                                    \
-        if (G8_DBG(2)) break;                                                               \
         G8_WRITE(q, (t) + 1);                                                               \
         __builtin_amdgcn_sched_barrier(0);      /* reload the SAME registers after the write */ \
         G8_LOAD(q, (t) + 2 < nk ? (t) + 2 : nk - 1);                                        \
@@ -1149,61 +927,28 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int EPI>
-hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
+template <int EPI, int NSPLIT>
+hipError_t launch_gemm_ns(const xb::GemmParams &p, hipStream_t stream)
 {
     const int MT = (p.M + GBM - 1) / GBM, NT = (p.Nn + GBN - 1) / GBN;
     const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
-    const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see the tile order in gemm_kernel
+    const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see gemm_tile_origin
     dim3 grid(8 * 32 * ((supers + 7) / 8)), block(GTHREADS);
-    const size_t lds = (size_t)2 * (p.nsplit != 1 ? 4 : 2) * GBM * 4 * sizeof(uint4);
-    static const int variant = [] {                 // XB_GEMM_KERNEL=1: the register-staged kernel (A/B runs)
-        const char *e = getenv("XB_GEMM_KERNEL");
-        return e ? atoi(e) : 8;
-    }();
-#ifdef XB_LSTM_STAMPS
-    if (const char *e = getenv("XB_GEMM_DBG")) const_cast<xb::GemmParams &>(p).dbg = atoi(e);
-#endif
-    if (p.nsplit == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm8r_kernel<EPI, 2>), grid, block, lds, stream, p);
-        return hipGetLastError();
-    }
-    if (variant == 8) {
-        if (p.nsplit == 3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((gemm8r_kernel<EPI, 3>), grid, block, lds, stream, p);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((gemm8r_kernel<EPI, 1>), grid, block, lds, stream, p);
-        }
-        return hipGetLastError();
-    }
-    if (variant == 9) {
-        if (p.nsplit == 3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<EPI, 3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((gemm8_kernel<EPI, 3>), grid, block, lds, stream, p);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<EPI, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((gemm8_kernel<EPI, 1>), grid, block, lds, stream, p);
-        }
-        return hipGetLastError();
-    }
-    if (p.nsplit == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, 3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm_kernel<EPI, 3>), grid, block, lds, stream, p);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<EPI, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm_kernel<EPI, 1>), grid, block, lds, stream, p);
-    }
+    const size_t lds = (size_t)2 * 4 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;    // [4 half-tiles][2 buffers][parts][128 rows x 64 B]
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8r_kernel<EPI, NSPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm8r_kernel<EPI, NSPLIT>), grid, block, lds, stream, p);
     return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
+{
+    switch (p.nsplit) {
+    case 1: return launch_gemm_ns<EPI, 1>(p, stream);
+    case 2: return launch_gemm_ns<EPI, 2>(p, stream);
+    default: return launch_gemm_ns<EPI, 3>(p, stream);
+    }
 }
 
 }  // namespace

@@ -63,7 +63,6 @@ struct GemmParams {
     int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only ; 2 = hi*hi + fp8 corrections (q8 images)
     int a_exp, b_exp;            // nsplit == 2: exponents of the A and B q8 images
     int out_exp;                 // nsplit == 2, EPI_SILU_SPLIT: exponent of the q8 image written to out_lo
-    int dbg;                     // diagnostic builds only (XB_LSTM_STAMPS): 1 skip MFMAs, 2 skip staging, 4 skip fragment reads
 };
 hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream);
 
