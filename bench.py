@@ -53,6 +53,24 @@ def cpu_baseline(sd, features, n_base, L, chunks, alphabet):
             "sample": "%d chunks x %d samples, %d-base CRF, fp32 C oracle (OpenMP), %.1f s" % (chunks, L, n_base, dt)}
 
 
+def measured_traffic(kernel_prefix, nb, batch, chunksize, precision):
+    """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 runs, gfx950 correction applied) -- only when they were taken on this configuration."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        c = d.get("config", {})
+        if (c.get("n_base"), c.get("batch_per_gpu"), c.get("chunksize"), c.get("precision")) != (nb, batch, chunksize, precision):
+            continue
+        for name, k in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix):
+                return k.get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +161,8 @@ def main():
     rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
     roofline = {"kernel": "lstm_kernel<%d,%d>" % (F // 16, {0: 3, 1: 1, 2: 2}[prec]), "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
+                "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision),
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches,
                 "note": "algorithmic fp32-equivalent FLOPs; f16x3 issues 3 fp16 MFMA products per FLOP pair, "
                         "f16f8 one fp16 product + one block-scaled FP8 MFMA (2x rate) for both corrections"}
@@ -153,7 +172,8 @@ def main():
     dec_avg_s = 1e-3 * dec_ms / max(dec_launches, 1)
     dec_gbs = a_dec / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
     roofline_decode = {"kernel": "crf_decode_kernel", "bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS, "traffic": None,
+                       "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS,
+                       "traffic": measured_traffic("crf_decode_kernel", nb, N, L, args.precision), "algorithmic_bytes": a_dec,
                        "avg_launch_ms": 1e3 * dec_avg_s, "launches": dec_launches,
                        "decode_only_samples_per_s": N * L / dec_avg_s if dec_avg_s > 0 else 0.0}
 
