@@ -36,7 +36,11 @@ struct xb_ctx {
     xb_config cfg{};
     int device = 0;
     int cu_count = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream (highest priority): everything except the overlapped GEMM slabs
+    hipStream_t stream2 = nullptr;   // low-priority stream: the next layer's input GEMM, slab by slab, beside the recurrence
+    std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
+    size_t dep_next = 0;
+    int overlap = 1, time_slabs = 16;   // XB_OVERLAP / XB_TIME_SLABS (upper bound; a slab is at least 125 steps)
     mutable std::string err;
     int T = 0, S = 0, hi = 0, O = 0, kp = 0, ld_nb = 0;
     bool weights_ready = false;
@@ -56,7 +60,7 @@ struct xb_ctx {
     float *d_signal = nullptr;
     half_t *im_hi = nullptr, *im_lo = nullptr;
     half_t *x_hi[2] = {}, *x_lo[2] = {};
-    float *gin = nullptr, *c_state = nullptr, *scores = nullptr;
+    float *gin = nullptr, *gin2 = nullptr, *c_state = nullptr, *scores = nullptr;
     half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
     float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
@@ -111,16 +115,18 @@ struct StageScope {
     xb_ctx *c;
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
-    StageScope(xb_ctx *ctx, int st, int launches) : c(ctx), stage(st)
+    hipStream_t st_;
+    StageScope(xb_ctx *ctx, int st, int launches, hipStream_t stream = nullptr)
+        : c(ctx), stage(st), st_(stream ? stream : ctx->stream)
     {
         c->stage_launches[st] += launches;
         if (c->profiling && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
-            hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st_);
     }
     ~StageScope()
     {
         if (a && b) {
-            hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st_);
             c->events.push_back({stage, a, b});
         }
     }
@@ -242,20 +248,61 @@ int check_device_error(xb_ctx *ctx)
 }
 
 // ---- encoder orchestration --------------------------------------------------------------
-int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const half_t *xin_lo, half_t *xout_hi,
-                   half_t *xout_lo)
+int precision_nsplit(const xb_ctx *ctx)
+{
+    return ctx->cfg.precision == XB_PREC_F16 ? 1 : (ctx->cfg.precision == XB_PREC_F16F8 ? 2 : 3);
+}
+
+// the GEMM that consumes a layer's output rows of time steps [ta, tb): the input projection of LSTM layer `layer`
+// (layer < 5, into `gin_out`) or the CRF linear layer (layer == 5, into the scores)
+struct NextGemm {
+    int layer;
+    const half_t *x_hi, *x_lo;
+    float *out;
+    int ldc, expand;
+};
+
+int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipStream_t st)
+{
+    const xb_config &c = ctx->cfg;
+    const int F = c.features;
+    xb::GemmParams g{};
+    const size_t r0 = (size_t)ta * n;
+    g.a_hi = ng.x_hi + r0 * F; g.a_lo = ng.x_lo + r0 * F;
+    g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = precision_nsplit(ctx);
+    g.ldc = ng.ldc; g.out_f32 = ng.out + r0 * ng.ldc;
+    if (ng.layer < 5) {
+        StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
+        g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
+        g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
+        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, st));
+    } else {
+        StageScope sc(ctx, XB_STAGE_LINEAR, 1, st);
+        g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo; g.Nn = ctx->O; g.bias = ctx->bl;
+        g.scale = c.scale; g.nb = c.n_base; g.expand = ng.expand; g.blank = c.blank_score;
+        g.a_exp = 8; g.b_exp = ctx->wl_exp;
+        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, st));
+    }
+    return XB_OK;
+}
+
+int next_dep(xb_ctx *ctx, hipEvent_t *ev)
+{
+    if (ctx->dep_next == ctx->deps.size()) {
+        hipEvent_t e;
+        XB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->deps.push_back(e);
+    }
+    *ev = ctx->deps[ctx->dep_next++];
+    return XB_OK;
+}
+
+// Recurrence of one layer from `gin` into (xout_hi, xout_lo).  With `next` set, the GEMM that consumes this layer's output
+// is issued as well: either afterwards on the main stream, or -- overlapped mode -- slab by slab on the second stream while
+// the recurrence (192 of the 256 CUs, latency bound) is still running; the main stream then waits for the last slab.
+int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout_hi, half_t *xout_lo, const NextGemm *next)
 {
     const int F = ctx->cfg.features, T = ctx->T;
-    const int nsplit = ctx->cfg.precision == XB_PREC_F16 ? 1 : (ctx->cfg.precision == XB_PREC_F16F8 ? 2 : 3);
-    {
-        StageScope sc(ctx, XB_STAGE_LSTM_IN, 1);
-        xb::GemmParams g{};
-        g.a_hi = xin_hi; g.a_lo = xin_lo; g.b_hi = ctx->wih_hi[layer]; g.b_lo = ctx->wih_lo[layer];
-        g.M = T * n; g.Nn = 4 * F; g.K = F; g.lda = F; g.ldb = F;
-        g.bias = ctx->lbias[layer]; g.out_f32 = ctx->gin; g.ldc = 4 * F; g.nsplit = nsplit;
-        g.a_exp = layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[layer];     // conv3 output / LSTM output
-        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, ctx->stream));
-    }
     const int members = xb::lstm_members(F), bn = xb::lstm_group_chunks();
     int mode = ctx->lstm_mode;
     const int gmax = ctx->cu_count / members;
@@ -263,21 +310,53 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const ha
     if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
     XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));
     xb::LstmParams p{};
-    p.gin = ctx->gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
+    p.gin = gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
     p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state; p.xh = ctx->xh;
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
-    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = nsplit; p.w_exp = ctx->whh_exp[layer];
+    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = precision_nsplit(ctx); p.w_exp = ctx->whh_exp[layer];
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
+    bool overlapped = false;
     if (mode == 2) {
         const int slab = gmax > 64 ? 64 * bn : gmax * bn;
+        // time slabs only with one chunk slab: the exchange buffer carries h across launches of the SAME chunks
+        int nts = T / 125 < ctx->time_slabs ? T / 125 : ctx->time_slabs;
+        overlapped = next && ctx->overlap && ctx->stream2 && n <= slab && nts >= 2;
+        if (!overlapped) nts = 1;
         int launches = 0;
-        for (int n0 = 0; n0 < n; n0 += slab) ++launches;
-        StageScope sc(ctx, XB_STAGE_LSTM_REC, launches);
-        for (int n0 = 0; n0 < n; n0 += slab) {
-            p.n0 = n0; p.nslab = (n - n0) < slab ? (n - n0) : slab;
-            p.s_begin = 0; p.s_end = T; p.persistent = 1;
-            XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
-            XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
+        for (int n0 = 0; n0 < n; n0 += slab) launches += nts;
+        unsigned arrivals = 0;       // per member and group so far in this layer (a launch of k steps arrives k - 1 times)
+        for (int i = 0; i < nts; ++i) {
+            const int s0 = (int)((long long)T * i / nts), s1 = (int)((long long)T * (i + 1) / nts);
+            {
+                StageScope sc(ctx, XB_STAGE_LSTM_REC, i == 0 ? launches : 0);
+                for (int n0 = 0; n0 < n; n0 += slab) {
+                    p.n0 = n0; p.nslab = (n - n0) < slab ? (n - n0) : slab;
+                    p.s_begin = s0; p.s_end = s1; p.persistent = 1; p.sync_base = arrivals;
+                    // counters are zeroed once per chunk slab; consecutive time slabs follow each other without a memset
+                    // in between, so the next slab's workgroups are dispatched the moment the previous slab retires
+                    if (i == 0 || n > slab)
+                        XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
+                    if (n > slab) p.sync_base = 0;
+                    XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
+                }
+            }
+            arrivals += (unsigned)(s1 - s0 - 1);
+            if (overlapped) {
+                hipEvent_t ev;
+                int rc = next_dep(ctx, &ev);
+                if (rc) return rc;
+                XB_HIP(ctx, hipEventRecord(ev, ctx->stream));
+                XB_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev, 0));
+                const int ta = p.reverse ? T - s1 : s0, tb = p.reverse ? T - s0 : s1;
+                if ((rc = launch_row_gemm(ctx, *next, n, ta, tb, ctx->stream2))) return rc;
+            }
+        }
+        if (overlapped) {
+            hipEvent_t ev;
+            int rc = next_dep(ctx, &ev);
+            if (rc) return rc;
+            XB_HIP(ctx, hipEventRecord(ev, ctx->stream2));
+            XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
         }
     } else {
         StageScope sc(ctx, XB_STAGE_LSTM_REC, T);
@@ -287,6 +366,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const half_t *xin_hi, const ha
             XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
         }
     }
+    if (next && !overlapped) return launch_row_gemm(ctx, *next, n, 0, T, ctx->stream);
     return XB_OK;
 }
 
@@ -295,7 +375,8 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
 {
     const xb_config &c = ctx->cfg;
     const int F = c.features, T = ctx->T;
-    const int nsplit = c.precision == XB_PREC_F16 ? 1 : (c.precision == XB_PREC_F16F8 ? 2 : 3);
+    const int nsplit = precision_nsplit(ctx);
+    ctx->dep_next = 0;
     {
         StageScope sc(ctx, XB_STAGE_CONV, 2);
         xb::ConvFrontParams cf{};
@@ -310,20 +391,20 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
         g.a_exp = 0; g.b_exp = ctx->w3_exp; g.out_exp = 0;
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_SILU_SPLIT, ctx->stream));
     }
+    // layer l reads gin[l & 1] while the next layer's input projection is written into the other buffer
+    float *gin[2] = {ctx->gin, ctx->gin2 ? ctx->gin2 : ctx->gin};
     int cur = 0;
+    {
+        const NextGemm first{0, ctx->x_hi[0], ctx->x_lo[0], gin[0], 4 * F, 0};
+        int rc = launch_row_gemm(ctx, first, n, 0, T, ctx->stream);
+        if (rc) return rc;
+    }
     for (int l = 0; l < 5; ++l) {
-        int rc = run_lstm_layer(ctx, l, n, ctx->x_hi[cur], ctx->x_lo[cur], ctx->x_hi[cur ^ 1], ctx->x_lo[cur ^ 1]);
+        NextGemm next{l + 1, ctx->x_hi[cur ^ 1], ctx->x_lo[cur ^ 1], l < 4 ? gin[(l + 1) & 1] : scores_out,
+                      l < 4 ? 4 * F : ldc, expand};
+        int rc = run_lstm_layer(ctx, l, n, gin[l & 1], ctx->x_hi[cur ^ 1], ctx->x_lo[cur ^ 1], &next);
         if (rc) return rc;
         cur ^= 1;
-    }
-    {
-        StageScope sc(ctx, XB_STAGE_LINEAR, 1);
-        xb::GemmParams g{};
-        g.a_hi = ctx->x_hi[cur]; g.a_lo = ctx->x_lo[cur]; g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo;
-        g.M = T * n; g.Nn = ctx->O; g.K = F; g.lda = F; g.ldb = F;
-        g.bias = ctx->bl; g.out_f32 = scores_out; g.ldc = ldc; g.scale = c.scale; g.nb = c.n_base;
-        g.expand = expand; g.blank = c.blank_score; g.nsplit = nsplit; g.a_exp = 8; g.b_exp = ctx->wl_exp;
-        XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, ctx->stream));
     }
     return XB_OK;
 }
@@ -422,7 +503,14 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         return rc;
     }
     ctx->cu_count = prop.multiProcessorCount;
-    XB_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        XB_CREATE_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
+        XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
+        if (const char *e = getenv("XB_OVERLAP")) ctx->overlap = atoi(e) != 0;
+        if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
+    }
 
     const size_t N = cfg->max_batch, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
     const size_t Cb = (size_t)S * (cfg->n_base + 1);
@@ -436,6 +524,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         rc = rc ? rc : dev_alloc(ctx, &ctx->x_lo[i], T * N * F);
     }
     rc = rc ? rc : dev_alloc(ctx, &ctx->gin, T * N * 4 * F);
+    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, T * N * 4 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
@@ -463,10 +552,13 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (auto &e : ctx->deps) (void)hipEventDestroy(e);
     for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto &b : ctx->bufs) hipFree(b.p);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 

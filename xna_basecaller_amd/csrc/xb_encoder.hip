@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (p.persistent && s > p.s_begin) {
                 // wait until every member of the group has published h_{t-1}
                 if (tid == 0) {
-                    const unsigned target = (unsigned)members * (unsigned)(s - p.s_begin);
+                    const unsigned target = (unsigned)members * (p.sync_base + (unsigned)(s - p.s_begin));
                     const unsigned long long t0 = __builtin_readcyclecounter();
                     int ok = 1;
                     // the counter is polled back to back (one L2 round trip per poll); the error word and the
@@ -866,9 +866,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
             }
         }
-        const bool more = s + 1 < p.s_end || !p.persistent;
-        if (more && s + 1 < T) {
-            // publish h_t for the group (rows beyond the slab are scratch rows of the exchange buffer)
+        if (s + 1 < T) {
+            // publish h_t for the group -- also on the last step of a launch: the next launch (next step, or next time
+            // slab) starts from the exchange buffer (rows beyond the slab are scratch rows of the exchange buffer)
             half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
             store16_sc1(xcur, vhi);
             if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);

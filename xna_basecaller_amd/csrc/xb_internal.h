@@ -80,7 +80,8 @@ struct LstmParams {
     int reverse;                 // time runs T-1..0
     int s_begin, s_end;          // recurrence steps [s_begin, s_end) of this launch (s = 0 is the first step)
     int persistent;              // 1: all steps in one launch with inter-workgroup sync
-    unsigned *sync;              // per-group arrival counters (zeroed before a persistent launch), stride 32 words
+    unsigned *sync;              // per-group monotonic arrival counters, stride 32 words (zeroed once per layer and chunk slab)
+    unsigned sync_base;          // arrivals per member already counted by earlier launches of this layer (time slabs)
     unsigned *error;             // set non-zero when a sync wait timed out
     int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8)
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
