@@ -38,6 +38,10 @@ struct xb_ctx {
     int cu_count = 256;
     hipStream_t stream = nullptr;    // main stream (highest priority): everything except the overlapped GEMM slabs
     hipStream_t stream2 = nullptr;   // low-priority stream: the next layer's input GEMM, slab by slab, beside the recurrence
+    hipStream_t stream3 = nullptr;   // low-priority stream: CRF decode of batch k beside the encoder of batch k+1
+    hipEvent_t dec_done[2] = {};     // decode that last read scores buffer p has finished
+    bool dec_pending[2] = {};
+    unsigned batch_idx = 0;
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
     size_t dep_next = 0;
     int overlap = 1, time_slabs = 16;   // XB_OVERLAP / XB_TIME_SLABS (upper bound; a slab is at least 125 steps)
@@ -60,7 +64,7 @@ struct xb_ctx {
     float *d_signal = nullptr;
     half_t *im_hi = nullptr, *im_lo = nullptr;
     half_t *x_hi[2] = {}, *x_lo[2] = {};
-    float *gin = nullptr, *gin2 = nullptr, *c_state = nullptr, *scores = nullptr;
+    float *gin = nullptr, *gin2 = nullptr, *c_state = nullptr, *scores = nullptr, *scores2 = nullptr;
     half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
     float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
@@ -410,8 +414,9 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
 }
 
 int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, int ld, const char *alphabet,
-               int8_t *d_labels, int8_t *d_seq, int32_t *d_len)
+               int8_t *d_labels, int8_t *d_seq, int32_t *d_len, hipStream_t st = nullptr)
 {
+    if (!st) st = ctx->stream;
     const xb_config &c = ctx->cfg;
     if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
     xb::DecodeParams p{};
@@ -431,9 +436,30 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
 #ifdef XB_LSTM_STAMPS
     if (const char *e = getenv("XB_DECODE_STOP")) p.debug_stop = atoi(e);
 #endif
-    StageScope sc(ctx, XB_STAGE_DECODE, 1);
-    hipError_t e = xb::launch_crf_decode(p, ctx->stream);
+    StageScope sc(ctx, XB_STAGE_DECODE, 1, st);
+    hipError_t e = xb::launch_crf_decode(p, st);
     if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? XB_ERR_INVALID : XB_ERR_HIP, "crf decode launch failed: %s", hipGetErrorString(e));
+    return XB_OK;
+}
+
+// every entry point except the asynchronous basecall first orders the main stream behind decodes still in flight on the
+// third stream (they share the decode workspaces and the score buffers)
+int join_async_decode(xb_ctx *ctx)
+{
+    for (int p = 0; p < 2; ++p)
+        if (ctx->dec_pending[p]) {
+            XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[p], 0));
+            ctx->dec_pending[p] = false;
+        }
+    return XB_OK;
+}
+
+int sync_all(xb_ctx *ctx)
+{
+    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) XB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    if (ctx->stream3) XB_HIP(ctx, hipStreamSynchronize(ctx->stream3));
+    ctx->dec_pending[0] = ctx->dec_pending[1] = false;
     return XB_OK;
 }
 
@@ -508,6 +534,8 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         XB_CREATE_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
         XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
+        XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, least));
+        for (int p = 0; p < 2; ++p) XB_CREATE_HIP(hipEventCreateWithFlags(&ctx->dec_done[p], hipEventDisableTiming));
         if (const char *e = getenv("XB_OVERLAP")) ctx->overlap = atoi(e) != 0;
         if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
     }
@@ -528,6 +556,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
+    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->scores2, T * N * (size_t)ctx->ld_nb);
     rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
@@ -554,11 +583,14 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    for (auto &e : ctx->dec_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->deps) (void)hipEventDestroy(e);
     for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto &b : ctx->bufs) hipFree(b.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     delete ctx;
 }
 
@@ -635,7 +667,8 @@ XB_API int xb_synchronize(xb_ctx *ctx)
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
-    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_all(ctx);
+    if (rc) return rc;
     return check_device_error(ctx);
 }
 
@@ -645,6 +678,7 @@ XB_API int xb_encode_dev(xb_ctx *ctx, const float *d_signal, int n, int expand_b
     if (rc) return rc;
     if (!d_signal || !d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = join_async_decode(ctx))) return rc;
     const int ldc = expand_blanks ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     return run_encoder(ctx, d_signal, n, expand_blanks ? 1 : 0, d_scores, ldc);
 }
@@ -655,6 +689,7 @@ XB_API int xb_encode(xb_ctx *ctx, const float *signal, int n, int expand_blanks,
     if (rc) return rc;
     if (!signal || !scores) return fail(ctx, XB_ERR_INVALID, "null host pointer");
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = join_async_decode(ctx))) return rc;
     XB_HIP(ctx, hipMemcpyAsync(ctx->d_signal, signal, sizeof(float) * (size_t)n * ctx->cfg.chunk_len,
                                hipMemcpyHostToDevice, ctx->stream));
     const int ldc = expand_blanks ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
@@ -672,6 +707,7 @@ XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int h
     if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
     if (!d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = join_async_decode(ctx)) return rc;
     const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, alphabet, d_labels, d_seq, d_seq_len);
 }
@@ -684,6 +720,7 @@ XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_bla
     if (!scores) return fail(ctx, XB_ERR_INVALID, "null host pointer");
     if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcj = join_async_decode(ctx)) return rcj;
     const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
     int rc = run_decode(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, alphabet, ctx->labels, seq ? ctx->seq : nullptr,
@@ -702,9 +739,27 @@ XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, con
     if (rc) return rc;
     if (!d_signal || !d_seq || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
     XB_HIP(ctx, hipSetDevice(ctx->device));
-    rc = run_encoder(ctx, d_signal, n, 0, ctx->scores, ctx->ld_nb);
+    if (!ctx->overlap || !ctx->stream3 || !ctx->scores2) {
+        rc = run_encoder(ctx, d_signal, n, 0, ctx->scores, ctx->ld_nb);
+        if (rc) return rc;
+        return run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len);
+    }
+    // asynchronous decode: the encoder of this batch writes score buffer p while the decode of the previous batch may
+    // still be reading buffer p ^ 1 on the third stream; the decode that used buffer p two calls ago must be done first
+    const int pb = (int)(ctx->batch_idx++ & 1u);
+    float *sc = pb ? ctx->scores2 : ctx->scores;
+    if (ctx->dec_pending[pb]) XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[pb], 0));
+    rc = run_encoder(ctx, d_signal, n, 0, sc, ctx->ld_nb);
     if (rc) return rc;
-    return run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len);
+    hipEvent_t enc;
+    if ((rc = next_dep(ctx, &enc))) return rc;
+    XB_HIP(ctx, hipEventRecord(enc, ctx->stream));
+    XB_HIP(ctx, hipStreamWaitEvent(ctx->stream3, enc, 0));
+    rc = run_decode(ctx, sc, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len, ctx->stream3);
+    if (rc) return rc;
+    XB_HIP(ctx, hipEventRecord(ctx->dec_done[pb], ctx->stream3));
+    ctx->dec_pending[pb] = true;
+    return XB_OK;
 }
 
 XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet, int8_t *seq,
@@ -718,6 +773,7 @@ XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const cha
                                hipMemcpyHostToDevice, ctx->stream));
     rc = xb_basecall_chunks_dev(ctx, ctx->d_signal, n, alphabet, ctx->seq, ctx->seq_len);
     if (rc) return rc;
+    if ((rc = join_async_decode(ctx))) return rc;
     XB_HIP(ctx, hipMemcpyAsync(seq, ctx->seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, ctx->stream));
     if (seq_len) XB_HIP(ctx, hipMemcpyAsync(seq_len, ctx->seq_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return xb_synchronize(ctx);
@@ -734,7 +790,7 @@ XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t lau
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
-    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     collect_events(ctx);
     for (int i = 0; i < XB_STAGE_COUNT; ++i) {
         if (ms) ms[i] = ctx->stage_ms[i];
@@ -746,7 +802,7 @@ XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t lau
 XB_API int xb_reset_stage_times(xb_ctx *ctx)
 {
     if (!ctx) return XB_ERR_INVALID;
-    XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     collect_events(ctx);
     for (int i = 0; i < XB_STAGE_COUNT; ++i) { ctx->stage_ms[i] = 0.f; ctx->stage_launches[i] = 0; }
     return XB_OK;
