@@ -551,8 +551,9 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         rc = rc ? rc : dev_alloc(ctx, &ctx->x_hi[i], T * N * F);
         rc = rc ? rc : dev_alloc(ctx, &ctx->x_lo[i], T * N * F);
     }
-    rc = rc ? rc : dev_alloc(ctx, &ctx->gin, T * N * 4 * F);
-    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, T * N * 4 * F);
+    // + 64 rows: the recurrence's LDS-DMA of a ragged last group reads (and ignores) up to 63 rows past the last chunk
+    rc = rc ? rc : dev_alloc(ctx, &ctx->gin, (T * N + 64) * 4 * F);
+    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, (T * N + 64) * 4 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);

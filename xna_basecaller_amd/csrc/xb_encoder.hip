@@ -22,6 +22,7 @@ using xb::half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
@@ -602,7 +603,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
     unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
     float *sC = reinterpret_cast<float *>(sT + NPARTS * 16 * ST_LD);                // [32 units][64 chunks] cell state
-    int *sFlag = reinterpret_cast<int *>(sC + LG_UNITS * LG_BN);
+    // input-projection tile of the step: [64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
+    unsigned char *sG = reinterpret_cast<unsigned char *>(sC + LG_UNITS * LG_BN);
+    int *sFlag = reinterpret_cast<int *>(sG + LG_BN * LG_UNITS * 16);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -664,22 +667,53 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     if (tid == 0) for (int i = 0; i < 8; ++i) sStamp[i] = 0;
     unsigned long long stamp_prev = __builtin_readcyclecounter();
 #endif
+    // The input projection of a step (gin: 64 chunks x 128 gate rows x 4 B = 32 KiB per workgroup) is pulled into LDS by
+    // LDS-DMA one step AHEAD, right after the exchange stores of the previous step: it is in flight during drain / arrive /
+    // poll instead of starting at the top of the step (where the polling wave's wait absorbed its whole HBM latency),
+    // it needs no registers, and the store drain becomes a counted wait (all but these eight youngest operations).
+    // Instruction q = 4 d + wid (d = 0..7) fills chunk rows 2q, 2q + 1: lane i -> row 8 d + 2 wid + (i >> 5), cell i & 31,
+    // source cell (i & 31) ^ (row & 7): the lane part of the address is the same for all eight instructions.  Rows
+    // past the slab's last chunk read whatever follows (other chunks' rows or the 64 slack rows behind the buffer):
+    // their results are never stored.
+    auto issue_gin_d = [&](int tn, int d) {
+        // lane part recomputed per call (a few VALU) rather than kept in a register across the MFMA loop, where it would be
+        // spilled and its reload (a scratch load + wait) would drain whatever is in flight
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const unsigned gin_lane = (unsigned)(((2 * wid + (lo >> 5)) * (4 * F) + (((lo & 31) ^ ((2 * wid + (lo >> 5)) & 7)) * 4)) * 4);
+        // wave-uniform base (SGPRs) + 32-bit lane byte offset
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(
+            p.gin + ((size_t)tn * N + cbase + 8 * d) * (4 * F) + (size_t)mb * (LG_UNITS * 4));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + gin_lane),
+                                         (__attribute__((address_space(3))) void *)(sG + (4 * d + wid) * 1024), 16, 0, 0);
+    };
+    auto issue_gin = [&](int tn) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) issue_gin_d(tn, d);
+    };
+    // (Requesting the tile still earlier -- in the free issue slots of the second-to-last piece, that piece ending on
+    // vmcnt(8) -- was measured too: the poll no longer waits for it, but the first-piece landing and the MFMA phase grow by
+    // as much: 76.1 vs 74.5 ms per five layers.)
+    // accumulators start from the input projection (+ biases): lane (chunk row r, unit u) reads cell u ^ (r & 7)
+    // (two lanes of a 16-lane read group share a bank slot: a 2-way conflict on eight reads per step)
+    auto acc_from_gin = [&](floatx16 (&acc)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int r = nt * 32 + (lane & 31);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int u = wid * 8 + 2 * rg + hsel;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sG + r * (LG_UNITS * 16) + ((u ^ (r & 7)) * 16));
+                acc[nt][4 * rg + 0] = v[0]; acc[nt][4 * rg + 1] = v[1];
+                acc[nt][4 * rg + 2] = v[2]; acc[nt][4 * rg + 3] = v[3];
+            }
+        }
+    };
+    issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
     for (int s = p.s_begin; s < p.s_end; ++s) {
         XB_STAMP(0);   // loop overhead / y stores of the previous step
         const int t = p.reverse ? T - 1 - s : s;
-
-        // accumulators start from the input projection (+ biases)
         floatx16 acc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float *g = p.gin + ((size_t)t * N + chunk[nt]) * (4 * F) + (size_t)ubase * 4;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float4 v = *reinterpret_cast<const float4 *>(g + (2 * rg + hsel) * 4);
-                acc[nt][4 * rg + 0] = v.x; acc[nt][4 * rg + 1] = v.y;
-                acc[nt][4 * rg + 2] = v.z; acc[nt][4 * rg + 3] = v.w;
-            }
-        }
 
         if (s > 0) {
             if (p.persistent && s > p.s_begin) {
@@ -734,9 +768,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             };
 #pragma unroll
             for (int d = 0; d < NDMA; ++d) issue_dma(0, d);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first piece and the gin tile (this wave's shares)
             __syncthreads();
             XB_STAMP(2);   // first piece landed
+            acc_from_gin(acc);
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
@@ -791,6 +826,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         if (2 * ks < NDMA) issue_dma(pc + 1, 2 * ks);
                         if (2 * ks + 1 < NDMA) issue_dma(pc + 1, 2 * ks + 1);
                     }
+
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
@@ -798,6 +834,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 __syncthreads();
                 XB_STAMP(7);   // piece DMA wait + barrier
             }
+        }
+
+        if (s == 0) {      // no recurrent term in the very first step: the accumulators are the input projection
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            acc_from_gin(acc);
         }
 
         // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
@@ -875,8 +917,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
         XB_STAMP(4);   // pointwise + exchange stores issued
         if (p.persistent && s + 1 < p.s_end) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-            __syncthreads();
+            // next step's gin tile (eight LDS-DMAs per wave), then every storing wave drains its exchange stores: all but
+            // the eight youngest operations (raw barrier: __syncthreads() would drain the DMAs as well; the LDS reads of
+            // the staging are retired here)
+            __builtin_amdgcn_sched_barrier(0);
+            issue_gin(p.reverse ? T - 2 - s : s + 1);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             XB_STAMP(5);   // stores drained
             if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             XB_STAMP(6);   // arrive
@@ -884,10 +932,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             __syncthreads();   // sT is rewritten next step
         }
         // layer output for the next layer: plain stores, nobody in this launch reads them
+        // (address recomputed from the thread index here: a value kept across the loop gets spilled, and its reload -- a
+        // scratch load with a vmcnt(0) behind it -- would wait for the gin DMAs just issued)
         {
-            const int n = cbase + orow;
+            int to = tid;
+            asm volatile("" : "+v"(to));
+            const int n = cbase + (to >> 2);
             if (n <= nlast) {
-                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + occ * 8;
+                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
                 *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
                 *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
             }
@@ -916,7 +968,7 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const int g8 = (ngroups + 7) & ~7;
     const int members = F / LG_UNITS;
     const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-                       sizeof(float) * LG_UNITS * LG_BN + 16 + 80;
+                       sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16 + 16 + 80;
     dim3 grid(g8 * members), block(256);
     if (p.nsplit == 3)
         hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
