@@ -345,7 +345,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 }
             }
             arrivals += (unsigned)(s1 - s0 - 1);
-            if (overlapped) {
+            if (overlapped && ctx->overlap == 1) {
                 hipEvent_t ev;
                 int rc = next_dep(ctx, &ev);
                 if (rc) return rc;
@@ -355,12 +355,14 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 if ((rc = launch_row_gemm(ctx, *next, n, ta, tb, ctx->stream2))) return rc;
             }
         }
-        if (overlapped) {
+        if (overlapped && ctx->overlap == 1) {
             hipEvent_t ev;
             int rc = next_dep(ctx, &ev);
             if (rc) return rc;
             XB_HIP(ctx, hipEventRecord(ev, ctx->stream2));
             XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+        } else if (overlapped) {
+            overlapped = false;     // XB_OVERLAP=2: the GEMM follows on the main stream
         }
     } else {
         StageScope sc(ctx, XB_STAGE_LSTM_REC, T);
@@ -536,7 +538,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
         XB_CREATE_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, least));
         for (int p = 0; p < 2; ++p) XB_CREATE_HIP(hipEventCreateWithFlags(&ctx->dec_done[p], hipEventDisableTiming));
-        if (const char *e = getenv("XB_OVERLAP")) ctx->overlap = atoi(e) != 0;
+        if (const char *e = getenv("XB_OVERLAP")) ctx->overlap = atoi(e);   // 0 serial, 1 overlapped, 2 time slabs but serial GEMM (A/B)
         if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
     }
 
