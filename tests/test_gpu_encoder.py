@@ -23,6 +23,22 @@ def _golden_case(name):
     return case, sd, z[name + "/signal"], z[name + "/scores"]
 
 
+@pytest.mark.parametrize("name", ["f32_nb6", "f32_nb4_long"])
+@pytest.mark.parametrize("lstm_mode", [1, 2])
+def test_encoder_small_golden_f16f8(name, lstm_mode):
+    """The default arithmetic (f16f8) against the fixtures made by the reference's own modules."""
+    case, sd, signal, ref = _golden_case(name)
+    F, nb = case["features"], len(case["labels"]) - 1
+    ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, case["L"], case["N"], precision=_lib.XB_PREC_F16F8,
+                       lstm_mode=lstm_mode)
+    ctx.load_state_dict(sd)
+    got = ctx.encode(signal[:, 0, :], expand_blanks=True)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err < 2e-4, err
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["f32_nb6", "f32_nb4_long", "f48_nb5", "f16_nb4"])
 @pytest.mark.parametrize("lstm_mode", [1, 2])
 def test_encoder_small_golden(name, lstm_mode):
