@@ -279,6 +279,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
         g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
+        g.gin_n = n;                                                           // member-major gin (xb_internal.h)
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, st));
     } else {
         StageScope sc(ctx, XB_STAGE_LINEAR, 1, st);

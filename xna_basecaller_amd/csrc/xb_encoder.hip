@@ -215,15 +215,19 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         bj[j] = (p.bias && n < p.Nn) ? p.bias[n] : 0.0f;
     }
-    if (EPI == xb::EPI_BIAS_F32 && m0 + GBM <= p.M && n0 + GBN <= p.Nn) {
-        // interior tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset
-        float *tile = p.out_f32 + (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);
-        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+    if (EPI == xb::EPI_BIAS_F32 && m0 + GBM <= p.M && n0 + GBN <= p.Nn && (p.gin_n == 0 || p.gin_n % GBM == 0)) {
+        // interior tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset.  With the member-major gin
+        // layout (whole tile inside one time step when gin_n is a multiple of the tile height) the wave's 64 columns lie in
+        // one member block and the row stride is 128 floats.
+        const int ld = p.gin_n ? 128 : p.ldc;
+        float *tile = p.gin_n ? p.out_f32 + xb::gin_offset((size_t)(m0 + wm * 128), n0 + wn * 64, p.gin_n, p.Nn)
+                              : p.out_f32 + (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);
+        const int loff = (4 * (lane >> 5)) * ld + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rowp[loff + j * 32] = acc[i][j][r] + bj[j];
             }
@@ -276,7 +280,7 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
                 if (m >= p.M) continue;
                 const float v = acc[i][j][r] + bias;
                 if (EPI == xb::EPI_BIAS_F32) {
-                    p.out_f32[(size_t)m * p.ldc + n] = v;
+                    p.out_f32[p.gin_n ? xb::gin_offset((size_t)m, n, p.gin_n, p.Nn) : (size_t)m * p.ldc + n] = v;
                 } else if (EPI == xb::EPI_SILU_SPLIT) {
                     if (p.nsplit == 2) {
                         half_t hi;
@@ -680,10 +684,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         // spilled and its reload (a scratch load + wait) would drain whatever is in flight
         int lo = lane;
         asm volatile("" : "+v"(lo));
-        const unsigned gin_lane = (unsigned)(((2 * wid + (lo >> 5)) * (4 * F) + (((lo & 31) ^ ((2 * wid + (lo >> 5)) & 7)) * 4)) * 4);
-        // wave-uniform base (SGPRs) + 32-bit lane byte offset
+        const unsigned gin_lane = (unsigned)(((2 * wid + (lo >> 5)) * 128 + (((lo & 31) ^ ((2 * wid + (lo >> 5)) & 7)) * 4)) * 4);
+        // wave-uniform base (SGPRs) + 32-bit lane byte offset; member-major gin (xb_internal.h): this workgroup's 64 chunk
+        // rows of 128 gate columns are contiguous
         const unsigned char *base = reinterpret_cast<const unsigned char *>(
-            p.gin + ((size_t)tn * N + cbase + 8 * d) * (4 * F) + (size_t)mb * (LG_UNITS * 4));
+            p.gin + (((size_t)tn * members + mb) * N + cbase + 8 * d) * 128);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + gin_lane),
                                          (__attribute__((address_space(3))) void *)(sG + (4 * d + wid) * 1024), 16, 0, 0);
     };

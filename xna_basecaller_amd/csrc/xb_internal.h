@@ -63,7 +63,16 @@ struct GemmParams {
     int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only ; 2 = hi*hi + fp8 corrections (q8 images)
     int a_exp, b_exp;            // nsplit == 2: exponents of the A and B q8 images
     int out_exp;                 // nsplit == 2, EPI_SILU_SPLIT: exponent of the q8 image written to out_lo
+    int gin_n;                   // EPI_BIAS_F32: > 0 selects the member-major gin layout (below) with gin_n chunks per time step
 };
+// gin layout (input projection of an LSTM layer, written by the GEMM, read by lstm_kernel): row m = t * n + chunk, column
+// c = unit * 4 + gate.  Stored member-major, [t][c / 128][chunk][c % 128]: the 64 chunks x 128 gate columns a recurrence
+// workgroup (32 units) needs per step are ONE contiguous 32 KiB block instead of 64 segments 4F floats apart.
+__host__ __device__ inline size_t gin_offset(size_t m, int c, int n, int cols)
+{
+    const size_t t = m / (size_t)n, chunk = m % (size_t)n;
+    return ((t * (size_t)(cols / 128) + (size_t)(c >> 7)) * (size_t)n + chunk) * 128 + (size_t)(c & 127);
+}
 hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream);
 
 // One LSTM layer's recurrence over a slab of chunks.  Gate pre-activations of the input
