@@ -11,13 +11,17 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no exceptions across the ABI.
  *   - every function returns XB_OK (0) or a negative xb_status; xb_last_error(ctx) gives text.
- *   - one xb_ctx per GPU; it owns a HIP stream and every device buffer it allocates.  A ctx is
+ *   - one xb_ctx per GPU; it owns its HIP streams (a main stream plus two low-priority side streams: the next
+ *     layer's input GEMM runs beside the current layer's recurrence, the CRF decode of one batch beside the encoder
+ *     of the next) and every device buffer it allocates.  A ctx is
  *     used by one thread at a time (the reference calls compute_scores from ONE pipeline
  *     thread, crf/basecall.py:109-111); distinct ctxs are independent.
  *   - "host" entry points take host buffers owned by the caller and block until the result is
  *     in them.  "_dev" entry points take device pointers valid on the ctx's device (e.g.
- *     torch tensor data_ptr()), enqueue on the ctx stream and return without waiting; call
- *     xb_synchronize before reading results.
+ *     torch tensor data_ptr()), enqueue on the ctx's streams and return without waiting.  The ONLY completion
+ *     point is xb_synchronize (it joins all of the ctx's streams): call it before reading results or reusing /
+ *     freeing the buffers passed in.  Consecutive xb_basecall_chunks_dev calls pipeline (decode of batch k overlaps
+ *     the encoder of batch k+1): give each in-flight batch its own d_seq / d_seq_len.
  *   - layouts are the reference's: signal (N, L) fp32 [= (N,1,L)], scores (T, N, C) fp32
  *     time-major, labels / seq (N, T) int8.
  */
