@@ -74,3 +74,35 @@ def test_basecall_reads_end_to_end():
         total += lab.size
         mism += int((lab != lab2).sum())
     assert mism <= total // 500, (mism, total)
+
+
+def test_pipelined_device_calls_match_blocking_calls():
+    """Several xb_basecall_chunks_dev calls in flight (decode of batch k beside the encoder of batch k+1, time-slab
+    recurrence with the next layer's GEMM on the second stream), ONE synchronize at the end: every batch must equal
+    what the blocking host entry point returns for it.  T = 400 makes the recurrence run as 3 time slabs."""
+    import torch
+    from conftest import encoder_shapes, seeded_state_dict
+    from xna_basecaller_amd import _lib
+
+    F, nb, L, N = 128, 5, 2000, 70
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=9)
+    ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
+    ctx.load_state_dict(sd)
+    alphabet = "NACGTX"
+    rng = np.random.default_rng(4)
+    batches = [rng.standard_normal((n, L)).astype(np.float32) for n in (70, 33, 70, 1, 64)]
+    expect = [ctx.basecall_chunks(x, alphabet) for x in batches]
+    dev = torch.device("cuda", 0)
+    d_in = [torch.from_numpy(x).to(dev) for x in batches]
+    d_seq = [torch.full((x.shape[0], ctx.T), -1, dtype=torch.int8, device=dev) for x in batches]
+    d_len = [torch.full((x.shape[0],), -1, dtype=torch.int32, device=dev) for x in batches]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for x, s, l in zip(d_in, d_seq, d_len):
+            ctx.basecall_chunks_dev(x.data_ptr(), x.shape[0], alphabet, s.data_ptr(), l.data_ptr())
+        ctx.synchronize()
+        for (eseq, elen), s, l in zip(expect, d_seq, d_len):
+            assert np.array_equal(l.cpu().numpy(), elen)
+            assert np.array_equal(s.cpu().numpy(), eseq)
+    ctx.close()
