@@ -178,3 +178,23 @@ def test_encoder_f16f8_full_size():
     err = np.abs(outs["persist"][:, :4] - ref)
     assert err[:, :3].max() < 2e-4, err[:, :3].max()
     assert err[:, 3].max() < 1e-3, err[:, 3].max()
+
+
+def test_encoder_more_groups_than_one_launch_holds():
+    """features 768, 600 chunks = 10 groups: a persistent launch holds 8 (one group of 24 workgroups per XCD), so the batch
+    runs as two chunk slabs (512 + a ragged 88) x two time slabs (T = 260), with every group keeping its own exchange and
+    counter slot across the launches.  Must equal the one-launch-per-step mode bit for bit, and the oracle on a sample."""
+    meta = json.load(open(os.path.join(GOLDEN, "encoder_meta.json")))["full"]
+    sd = seeded_state_dict(meta["keys"], meta["shapes"], meta["seed"])
+    N, L = 600, 1300
+    x = np.random.default_rng(12).standard_normal((N, L)).astype(np.float32)
+    outs = {}
+    for name, mode in [("step", 1), ("persist", 2)]:
+        ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        outs[name] = ctx.encode(x, expand_blanks=False)
+        ctx.close()
+    assert np.array_equal(outs["step"], outs["persist"])
+    pick = [0, 511, 512, 599]
+    ref = oracle.encode(x[pick], sd, 768, 6, 3, expand_blanks=False)
+    assert np.abs(outs["persist"][:, pick] - ref).max() < 2e-4

@@ -310,7 +310,10 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     const int F = ctx->cfg.features, T = ctx->T;
     const int members = xb::lstm_members(F), bn = xb::lstm_group_chunks();
     int mode = ctx->lstm_mode;
-    const int gmax = ctx->cu_count / members;
+    // groups per persistent launch: every workgroup must be resident at once, and workgroups are dealt to the 8 XCDs
+    // strictly round-robin (block b -> XCD b % 8), i.e. groups g, g + 8, .. share ONE XCD's CUs: F = 768 (24 members per
+    // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
+    const int gmax = 8 * ((ctx->cu_count / 8) / members);
     if (mode == 0) mode = gmax >= 1 ? 2 : 1;
     if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
     XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));
@@ -323,12 +326,16 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     bool overlapped = false;
     if (mode == 2) {
         const int slab = gmax > 64 ? 64 * bn : gmax * bn;
-        // time slabs only with one chunk slab: the exchange buffer carries h across launches of the SAME chunks
+        // the exchange buffer and the counters have 64 group slots: with the whole batch inside them every group keeps its
+        // own slot across launches, so chunk slabs and time slabs combine freely; a larger batch falls back to one launch
+        // per chunk slab over all steps with launch-local slots
+        const bool global_groups = n <= 64 * bn;
         int nts = T / 125 < ctx->time_slabs ? T / 125 : ctx->time_slabs;
-        overlapped = next && ctx->overlap && ctx->stream2 && n <= slab && nts >= 2;
+        overlapped = next && ctx->overlap && ctx->stream2 && global_groups && nts >= 2;
         if (!overlapped) nts = 1;
         int launches = 0;
         for (int n0 = 0; n0 < n; n0 += slab) launches += nts;
+        if (global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
         unsigned arrivals = 0;       // per member and group so far in this layer (a launch of k steps arrives k - 1 times)
         for (int i = 0; i < nts; ++i) {
             const int s0 = (int)((long long)T * i / nts), s1 = (int)((long long)T * (i + 1) / nts);
@@ -336,12 +343,12 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 StageScope sc(ctx, XB_STAGE_LSTM_REC, i == 0 ? launches : 0);
                 for (int n0 = 0; n0 < n; n0 += slab) {
                     p.n0 = n0; p.nslab = (n - n0) < slab ? (n - n0) : slab;
-                    p.s_begin = s0; p.s_end = s1; p.persistent = 1; p.sync_base = arrivals;
-                    // counters are zeroed once per chunk slab; consecutive time slabs follow each other without a memset
-                    // in between, so the next slab's workgroups are dispatched the moment the previous slab retires
-                    if (i == 0 || n > slab)
-                        XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
-                    if (n > slab) p.sync_base = 0;
+                    p.s_begin = s0; p.s_end = s1; p.persistent = 1;
+                    // counters are zeroed once per layer (above): consecutive launches follow each other without a memset in
+                    // between, so the next launch's workgroups are dispatched the moment the previous one retires
+                    p.grp0 = global_groups ? n0 / bn : 0;
+                    p.sync_base = global_groups ? arrivals : 0;
+                    if (!global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
                     XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
                 }
             }
@@ -366,6 +373,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
             overlapped = false;     // XB_OVERLAP=2: the GEMM follows on the main stream
         }
     } else {
+        if (n > 64 * bn) return fail(ctx, XB_ERR_INVALID, "one-launch-per-step LSTM mode handles at most %d chunks per batch", 64 * bn);
         StageScope sc(ctx, XB_STAGE_LSTM_REC, T);
         p.n0 = 0; p.nslab = n; p.persistent = 0;
         for (int s = 0; s < T; ++s) {

@@ -661,9 +661,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel];
     }
 
-    unsigned *cnt = p.sync + (size_t)grp * 32;
+    unsigned *cnt = p.sync + (size_t)(p.grp0 + grp) * 32;
     // exchange buffer of this group: [parity][part][64 rows][F]
-    half_t *xg = p.xh + (size_t)grp * (2 * 2 * LG_BN * F);
+    half_t *xg = p.xh + (size_t)(p.grp0 + grp) * (2 * 2 * LG_BN * F);
     constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
 
 #ifdef XB_LSTM_STAMPS

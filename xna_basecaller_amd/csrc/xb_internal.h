@@ -86,6 +86,9 @@ struct LstmParams {
     half_t *xh;                  // exchange buffer [groups][2 parity][2 parts][64][F] (h of the previous step)
     int T, N, F;
     int n0, nslab;               // chunks [n0, n0+nslab) are processed by this launch
+    int grp0;                    // index of this launch's first group in the exchange buffer and the counters (n0 / 64 when the
+                                 // whole batch fits the 64 group slots, so that h and the counters survive between the launches
+                                 // of different chunk slabs and time slabs; else 0)
     int reverse;                 // time runs T-1..0
     int s_begin, s_end;          // recurrence steps [s_begin, s_end) of this launch (s = 0 is the first step)
     int persistent;              // 1: all steps in one launch with inter-workgroup sync
