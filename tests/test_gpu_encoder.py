@@ -198,3 +198,23 @@ def test_encoder_more_groups_than_one_launch_holds():
     pick = [0, 511, 512, 599]
     ref = oracle.encode(x[pick], sd, 768, 6, 3, expand_blanks=False)
     assert np.abs(outs["persist"][:, pick] - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("features,N", [(512, 1100), (256, 2100), (384, 1030)])
+def test_encoder_group_limit_other_feature_sizes(features, N):
+    """16 / 8 / 12 member workgroups per group -> 2 / 4 / 2 groups per XCD and launch: batches just past one launch's
+    capacity (1024 / 2048 / 1024 chunks), ragged last group; persistent == one launch per step, bit for bit."""
+    nb, L = 4, 300
+    keys, shapes = encoder_shapes(features, nb)
+    sd = seeded_state_dict(keys, shapes, seed=features)
+    x = np.random.default_rng(features).standard_normal((N, L)).astype(np.float32)
+    outs = []
+    for mode in (1, 2):
+        ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        outs.append(ctx.encode(x, expand_blanks=False))
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+    pick = [0, N // 2, N - 1]
+    ref = oracle.encode(x[pick], sd, features, nb, 3, expand_blanks=False)
+    assert np.abs(outs[1][:, pick] - ref).max() < 2e-4
