@@ -218,3 +218,27 @@ def test_encoder_group_limit_other_feature_sizes(features, N):
     pick = [0, N // 2, N - 1]
     ref = oracle.encode(x[pick], sd, features, nb, 3, expand_blanks=False)
     assert np.abs(outs[1][:, pick] - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("features,nb,L,N", [(64, 5, 5, 3), (64, 5, 10, 70), (768, 6, 15, 65), (128, 4, 23, 1),
+                                             (768, 5, 640, 513)])
+def test_encoder_edge_shapes(features, nb, L, N):
+    """T = 1, 2, 3 (only the first-step path of the recurrence, the one-step-ahead gin prefetch with nothing to prefetch),
+    L not a multiple of the stride, a single chunk, and one chunk more than a launch holds at features 768."""
+    keys, shapes = encoder_shapes(features, nb)
+    sd = seeded_state_dict(keys, shapes, seed=features + L)
+    x = np.random.default_rng(L).standard_normal((N, L)).astype(np.float32)
+    outs = []
+    for mode in (1, 2):
+        ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        outs.append(ctx.encode(x, expand_blanks=False))
+        if mode == 2:
+            seq, lens = ctx.basecall_chunks(x, "NACGTXY"[:nb + 1])
+            lab = oracle.decode(ctx.encode(x, expand_blanks=True), nb, 3)["labels"]
+            assert np.array_equal(lens, (lab != 0).sum(axis=1))
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+    pick = sorted({0, N // 2, N - 1})
+    ref = oracle.encode(x[pick], sd, features, nb, 3, expand_blanks=False)
+    assert np.abs(outs[1][:, pick] - ref).max() < 2e-4
