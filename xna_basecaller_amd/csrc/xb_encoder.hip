@@ -975,12 +975,19 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
                        sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16 + 16 + 80;
     dim3 grid(g8 * members), block(256);
-    if (p.nsplit == 3)
+    if (p.nsplit == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
-    else if (p.nsplit == 2)
+    } else if (p.nsplit == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((lstm_kernel<KS, 2>), grid, block, lds, stream, p);
-    else
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((lstm_kernel<KS, 1>), grid, block, lds, stream, p);
+    }
     return hipGetLastError();
 }
 
