@@ -548,7 +548,7 @@ hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
 template <int NB>
 hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    switch (xb::decode_lanes_per_state(p.S)) {
+    switch (xb::decode_lanes_per_state(p.S, p.N)) {
     case 4: return launch_nb_lps<NB, 4>(p, vw, stream);
     case 2: return launch_nb_lps<NB, 2>(p, vw, stream);
     default: return launch_nb_lps<NB, 1>(p, vw, stream);
@@ -559,15 +559,19 @@ hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 
 namespace xb {
 
-int decode_lanes_per_state(int S)
+int decode_lanes_per_state(int S, int N)
 {
     if (const char *e = getenv("XB_DECODE_LPS")) {
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4) && v * S <= 512) return v;
     }
-    // measured on MI355X (N = 512, T = 2000): two lanes per state win while the block stays <= 256 threads
-    // (S = 64: 4.7 vs 5.0 ms, S = 125: 5.5 vs 6.8 ms); at S = 216 a 512-thread block loses (9.7 vs 8.5 ms)
-    return 2 * S <= 256 ? 2 : 1;
+    // measured on MI355X (T = 2000).  The kernel is VALU-issue bound, lane clusters duplicate the per-state work: two lanes
+    // per state win while the block stays <= 256 threads and the batch leaves the CUs few workgroups each (N = 512, S = 64:
+    // 4.7 vs 4.9 ms, S = 125: 5.4 vs 6.7 ms; S = 216 in a 512-thread block loses, 9.7 vs 8.5 ms); with many chunks per CU one
+    // lane per state is ahead for the small state space (N = 2048, S = 64: 6.9 vs 8.1 ms) but not for S = 125 (16.9 vs 16.0)
+    if (2 * S > 256) return 1;
+    if (S <= 64 && N >= 1024) return 1;
+    return 2;
 }
 
 // Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:

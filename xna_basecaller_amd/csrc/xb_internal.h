@@ -24,7 +24,7 @@ struct DecodeParams {
     int debug_stop;               // diagnostic builds only (XB_LSTM_STAMPS): return after sweep 1 / 2
 };
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream);
-int decode_lanes_per_state(int S);   // 1, 2 or 4 lanes serve one CRF state (env XB_DECODE_LPS overrides for tests)
+int decode_lanes_per_state(int S, int N);   // 1, 2 or 4 lanes serve one CRF state (env XB_DECODE_LPS overrides for tests)
 
 // ---------------------------------------------------------------- encoder (xb_encoder.hip)
 
