@@ -229,7 +229,8 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
             for (int r = 0; r < 16; ++r) {
                 float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) rowp[loff + j * 32] = acc[i][j][r] + bj[j];
+                // non-temporal: 12.6 GB per layer that nobody reads again before the L2 / Infinity Cache have turned over
+                for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
             }
         return;
     }
