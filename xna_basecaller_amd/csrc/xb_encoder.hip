@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         const unsigned char *base = reinterpret_cast<const unsigned char *>(
             p.gin + (((size_t)tn * members + mb) * N + cbase + 8 * d) * 128);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + gin_lane),
-                                         (__attribute__((address_space(3))) void *)(sG + (4 * d + wid) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(sG + (4 * d + wid) * 1024), 16, 0, 2 /* nt: read once */);
     };
     auto issue_gin = [&](int tn) {
 #pragma unroll
