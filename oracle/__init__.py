@@ -11,6 +11,8 @@ from .oracle import (  # noqa: F401
     lib,
     crf_idx,
     decode,
+    decode_logdomain,
+    decode_scaled,
     pack,
     decode_batch,
     conv1d_silu,

@@ -41,6 +41,8 @@ def lib():
         _lib.xo_logf.restype = C.c_float
         _lib.xo_logf.argtypes = [C.c_float]
         _lib.xo_decode.restype = C.c_int
+        _lib.xo_decode_logdomain.restype = C.c_int
+        _lib.xo_decode_scaled.restype = C.c_int
         _lib.xo_lstm.restype = C.c_int
         _lib.xo_linear_crf.restype = C.c_int
         _lib.xo_encode.restype = C.c_int
@@ -85,12 +87,7 @@ def crf_idx(n_base, state_len):
     return idx
 
 
-def decode(scores, n_base, state_len, blank_score=None, want=()):
-    """
-    scores (T,N,C) fp32; C = S*(nb+1) (blank column present) or, with blank_score given and
-    C = S*nb, the blank is the constant.  Returns dict with 'labels' (N,T) int8 and any of
-    want = ('alpha','beta','logz','post','amax','bmax').
-    """
+def _decode_args(scores, n_base, state_len, blank_score):
     scores = _f32(scores)
     T, N, Cin = scores.shape
     S, E = n_base ** state_len, n_base + 1
@@ -100,17 +97,72 @@ def decode(scores, n_base, state_len, blank_score=None, want=()):
         has_blank, blank = 0, float(blank_score)
     else:
         raise ValueError("scores last dim %d matches neither S*E=%d nor S*nb=%d" % (Cin, S * E, S * n_base))
+    return scores, T, N, S, E, has_blank, blank
+
+
+def decode(scores, n_base, state_len, blank_score=None, want=()):
+    """
+    The decode contract (xna_oracle.c header).  scores (T,N,C) fp32; C = S*(nb+1) (blank column present) or,
+    with blank_score given and C = S*nb, the blank is the constant.  Returns dict with 'labels' (N,T) int8 and
+    any of want = ('alpha','beta','logz','post','qlog','amax','bmax').
+    """
+    scores, T, N, S, E, has_blank, blank = _decode_args(scores, n_base, state_len, blank_score)
     out = {"labels": np.empty((N, T), dtype=np.int8)}
     shapes = {"alpha": (T + 1, N, S), "beta": (T + 1, N, S), "logz": (N,), "post": (T, N, S * E),
-              "amax": (T + 1, N, S), "bmax": (T + 1, N, S)}
+              "qlog": (T, N, S * E), "amax": (T + 1, N, S), "bmax": (T + 1, N, S)}
     for k in want:
         out[k] = np.zeros(shapes[k], dtype=np.float32)
     rc = lib().xo_decode(_p(scores), C.c_int(T), C.c_int(N), C.c_int(n_base), C.c_int(state_len),
                          C.c_int(has_blank), C.c_float(blank), _p(out["labels"], i8p),
                          _p(out.get("alpha")), _p(out.get("beta")), _p(out.get("logz")),
-                         _p(out.get("post")), _p(out.get("amax")), _p(out.get("bmax")))
+                         _p(out.get("post")), _p(out.get("qlog")), _p(out.get("amax")), _p(out.get("bmax")))
     if rc:
         raise MemoryError("xo_decode failed")
+    return out
+
+
+def decode_scaled(scores, n_base, state_len, blank_score=None, want=()):
+    """
+    NOT the contract: the same decode on scaled probabilities (float64-grade accuracy in fp32; census comparison
+    model).  want = ('avec','bvec','aexp','bexp','logz','post','qlog','amax','bmax').
+    """
+    scores, T, N, S, E, has_blank, blank = _decode_args(scores, n_base, state_len, blank_score)
+    out = {"labels": np.empty((N, T), dtype=np.int8)}
+    shapes = {"avec": (T + 1, N, S), "bvec": (T + 1, N, S), "logz": (N,), "post": (T, N, S * E),
+              "qlog": (T, N, S * E), "amax": (T + 1, N, S), "bmax": (T + 1, N, S)}
+    for k in want:
+        if k in ("aexp", "bexp"):
+            out[k] = np.zeros((T + 1, N), dtype=np.int32)
+        else:
+            out[k] = np.zeros(shapes[k], dtype=np.float32)
+    rc = lib().xo_decode_scaled(_p(scores), C.c_int(T), C.c_int(N), C.c_int(n_base), C.c_int(state_len),
+                                C.c_int(has_blank), C.c_float(blank), _p(out["labels"], i8p),
+                                _p(out.get("avec")), _p(out.get("bvec")), _p(out.get("aexp"), i32p),
+                                _p(out.get("bexp"), i32p), _p(out.get("logz")), _p(out.get("post")),
+                                _p(out.get("qlog")), _p(out.get("amax")), _p(out.get("bmax")))
+    if rc:
+        raise MemoryError("xo_decode_scaled failed")
+    return out
+
+
+def decode_logdomain(scores, n_base, state_len, blank_score=None, libm=False, want=(), softmax=False):
+    """
+    NOT the contract: the plain log-domain fp32 evaluation (what a seqdist-style kernel computes), with the
+    polynomial exp/log or libm's (softmax=True: libm with seqdist's per-time-step softmax normalisation of the
+    posteriors).  Returns 'labels' and any of want = ('gap','logz','post'); 'gap' (N,T) is the
+    winning max-marginal minus the best max-marginal of any edge carrying a different label.
+    """
+    scores, T, N, S, E, has_blank, blank = _decode_args(scores, n_base, state_len, blank_score)
+    out = {"labels": np.empty((N, T), dtype=np.int8)}
+    shapes = {"gap": (N, T), "logz": (N,), "post": (T, N, S * E)}
+    for k in want:
+        out[k] = np.zeros(shapes[k], dtype=np.float32)
+    rc = lib().xo_decode_logdomain(_p(scores), C.c_int(T), C.c_int(N), C.c_int(n_base), C.c_int(state_len),
+                                   C.c_int(has_blank), C.c_float(blank), C.c_int(2 if softmax else int(bool(libm))),
+                                   _p(out["labels"], i8p), _p(out.get("gap")), _p(out.get("logz")),
+                                   _p(out.get("post")))
+    if rc:
+        raise MemoryError("xo_decode_logdomain failed")
     return out
 
 

@@ -22,20 +22,28 @@
  * and IS pinned: tests/golden/ holds outputs of the reference's own nn.py modules run in
  * this container (tests/golden/make_golden.py).
  *
- * Floating-point contract of the decode (shared, by specification, with the HIP kernels;
- * the two implementations are written independently):
- *   - all arithmetic in IEEE binary32, round-to-nearest-even, no contraction
+ * Floating-point contract of the decode (shared, by specification, with the HIP kernels; the two
+ * implementations are written independently):
+ *   - all arithmetic in IEEE binary32, round-to-nearest-even, subnormals kept, no contraction
  *     (build with -ffp-contract=off), fused multiply-add only where fmaf() is written;
- *   - exp/log are the fixed polynomial routines xo_expf/xo_logf below (cephes-style),
- *     NOT libm, so that a CPU and a GPU produce the same bits;
- *   - logsumexp over a list x_0..x_{n-1}:  m = max_k x_k;  s = exp(x_0-m); s += exp(x_k-m)
- *     for k=1..n-1 in list order;  result = m + log(s);
+ *   - exp/log are the fixed polynomial routines xo_expf/xo_logf below (cephes-style; exp clamps its
+ *     argument to [-87, 88], log evaluates its polynomial in Estrin form), NOT libm, so that a CPU
+ *     and a GPU produce the same bits;
+ *   - logsumexp over a list x_0..x_{n-1} (xo_lse):  m = max_k x_k;  s = exp(x_0-m); s += exp(x_k-m)
+ *     for k=1..n-1 in list order;  result = m + log(s)  (seqdist's CUDA logsumexp sums in this order);
+ *     the final logZ = logsumexp_j(alpha_T[j]) sums in order j = 0..S-1;
  *   - in-edges of state j are listed k = 0..nb (k=0 is the stay/blank edge);
  *     out-edges of state i are listed stay first, then new base b = 0..nb-1;
  *   - posterior of edge (t,j,k):  P = exp(((alpha_t[src] + M) + beta_{t+1}[j]) - logZ),
- *     Q = log(P + 1e-8f);   logZ = logsumexp_j(alpha_T[j]) in order j = 0..S-1;
+ *     Q = log(P + 1e-8f);
  *   - max-marginal of edge c=j*E+k at time t: (amax_t[src] + Q) + bmax_{t+1}[j];
  *     label[t] = (lowest flat index attaining the maximum) % E.
+ * The recursions stay in the LOG domain on purpose: alpha ~ 1e3..1e4 is then rounded to an ulp of
+ * 1e-4..1e-3 at every step, which absorbs the last-bit differences between any two accurate exp/log
+ * implementations -- differently rounded log-domain builds (this contract, libm, libm with seqdist's
+ * softmax-normalised posteriors) differ in a few labels per million time steps of the census
+ * (tools/decode_census.py), a float64-accurate evaluation in ~400 per million.  xo_decode_scaled() and xo_decode_logdomain() are those comparison
+ * models, NOT part of the contract.
  */
 #include <math.h>
 #include <stdint.h>
@@ -55,11 +63,11 @@
 static inline float xo_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t xo_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* exp(x): 0 for x < -87, argument clamped to 88 above. */
+/* exp(x) with the argument clamped to [-87, 88] (no flush to zero: exp(-87) = 1.6e-38 stands for anything smaller). */
 static inline float xo_expf_i(float x)
 {
-    if (x < -87.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
     float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -76,7 +84,8 @@ static inline float xo_expf_i(float x)
     return y * s;
 }
 
-/* log(x) for normal positive x. */
+/* log(x) for normal positive x.  The degree-8 polynomial is evaluated in Estrin form (dependency depth 4 instead of 8:
+ * the log sits on the critical path of every time step of the recursions). */
 static inline float xo_logf_i(float x)
 {
     uint32_t ix = xo_f2bits(x);
@@ -85,15 +94,17 @@ static inline float xo_logf_i(float x)
     if (m > 1.41421356237309505f) { m = m * 0.5f; e += 1; }
     float f = m - 1.0f;
     float z = f * f;
-    float p = 7.0376836292e-2f;
-    p = fmaf(p, f, -1.1514610310e-1f);
-    p = fmaf(p, f, 1.1676998740e-1f);
-    p = fmaf(p, f, -1.2420140846e-1f);
-    p = fmaf(p, f, 1.4249322787e-1f);
-    p = fmaf(p, f, -1.6668057665e-1f);
-    p = fmaf(p, f, 2.0000714765e-1f);
-    p = fmaf(p, f, -2.4999993993e-1f);
-    p = fmaf(p, f, 3.3333331174e-1f);
+    float z2 = z * z;
+    float z4 = z2 * z2;
+    /* p(f) = c0 + c1 f + ... + c8 f^8 */
+    float q01 = fmaf(-2.4999993993e-1f, f, 3.3333331174e-1f);
+    float q23 = fmaf(-1.6668057665e-1f, f, 2.0000714765e-1f);
+    float q45 = fmaf(-1.2420140846e-1f, f, 1.4249322787e-1f);
+    float q67 = fmaf(-1.1514610310e-1f, f, 1.1676998740e-1f);
+    float q03 = fmaf(q23, z, q01);
+    float q47 = fmaf(q67, z, q45);
+    float q07 = fmaf(q47, z2, q03);
+    float p = fmaf(7.0376836292e-2f, z4, q07);
     float y = (f * z) * p;
     float fe = (float)e;
     y = fmaf(fe, -2.12194440e-4f, y);
@@ -133,8 +144,20 @@ XO_API void xo_crf_idx(int nb, int sl, int32_t *idx)
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* decode_batch (crf/model.py:215-218)                                                   */
+/* decode_batch (crf/model.py:215-218) -- THE CONTRACT                                   */
 /* ------------------------------------------------------------------------------------ */
+
+/* logsumexp of x[0..n): m = max; s = exp(x_0 - m), s += exp(x_k - m) for k = 1..n-1 in list order; m + log(s).
+ * (Sequential order on purpose: it is the order of seqdist's CUDA logsumexp, and the census shows that the summation
+ * order is what moves alpha's last bit most often.) */
+static inline float xo_lse(const float *x, int n)
+{
+    float m = x[0];
+    for (int k = 1; k < n; ++k) m = x[k] > m ? x[k] : m;
+    float s = xo_expf_i(x[0] - m);
+    for (int k = 1; k < n; ++k) s += xo_expf_i(x[k] - m);
+    return m + xo_logf_i(s);
+}
 
 /*
  * scores : (T, N, Cin) fp32.  has_blank != 0: Cin = S*E with the stay score in column 0 of
@@ -142,11 +165,368 @@ XO_API void xo_crf_idx(int nb, int sl, int32_t *idx)
  *          has_blank == 0: Cin = S*nb and the stay score is the constant `blank`.
  * labels : (N, T) int8 out -- argmax % E per time step (0 = no base emitted).
  * Optional outputs (may be NULL): alpha (T+1,N,S), beta (T+1,N,S), logz (N),
- *          post (T,N,S*E) posteriors P, amax (T+1,N,S), bmax (T+1,N,S).
+ *          post (T,N,S*E) posteriors P, qlog (T,N,S*E) = log(P + 1e-8), amax (T+1,N,S), bmax (T+1,N,S).
  */
 XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_blank, float blank,
                      int8_t *labels, float *alpha_out, float *beta_out, float *logz_out,
-                     float *post_out, float *amax_out, float *bmax_out)
+                     float *post_out, float *qlog_out, float *amax_out, float *bmax_out)
+{
+    const int S = (int)ipow(nb, sl), E = nb + 1, C = S * E;
+    const int Cin = has_blank ? C : S * nb;
+    const int hi = (int)ipow(nb, sl - 1);
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)C);
+    if (!idx) return -1;
+    xo_crf_idx(nb, sl, idx);
+    int err = 0;
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        const size_t TS = (size_t)(T + 1) * S;
+        float *al = (float *)malloc(sizeof(float) * TS);
+        float *be = (float *)malloc(sizeof(float) * TS);
+        float *bm = (float *)malloc(sizeof(float) * TS);
+        float *M = (float *)malloc(sizeof(float) * (size_t)C);
+        float *Q = (float *)malloc(sizeof(float) * (size_t)T * C);
+        float *am = (float *)malloc(sizeof(float) * 2 * (size_t)S);
+        if (!al || !be || !bm || !M || !Q || !am) {
+            err = -1;
+            free(al); free(be); free(bm); free(M); free(Q); free(am);
+            continue;
+        }
+#define LOADM(t)                                                                                    \
+    do {                                                                                            \
+        const float *row = scores + ((size_t)(t) * N + n) * Cin;                                    \
+        if (has_blank) memcpy(M, row, sizeof(float) * (size_t)C);                                   \
+        else for (int j_ = 0; j_ < S; ++j_) {                                                       \
+            M[j_ * E] = blank;                                                                      \
+            for (int k_ = 1; k_ < E; ++k_) M[j_ * E + k_] = row[j_ * nb + k_ - 1];                  \
+        }                                                                                           \
+    } while (0)
+
+        /* ---- Log semiring forward: alpha ---- */
+        for (int j = 0; j < S; ++j) al[j] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            LOADM(t);
+            const float *a0 = al + (size_t)t * S;
+            float *a1 = al + (size_t)(t + 1) * S;
+            for (int j = 0; j < S; ++j) {
+                float x[16] = {0};
+                for (int k = 0; k < E; ++k) x[k] = M[j * E + k] + a0[idx[j * E + k]];
+                a1[j] = xo_lse(x, E);
+            }
+        }
+        float logZ;
+        {   /* logsumexp over the final states, summed sequentially in state order */
+            const float *aT = al + (size_t)T * S;
+            float m = -INFINITY;
+            for (int j = 0; j < S; ++j) m = aT[j] > m ? aT[j] : m;
+            float s = xo_expf_i(aT[0] - m);
+            for (int j = 1; j < S; ++j) s += xo_expf_i(aT[j] - m);
+            logZ = m + xo_logf_i(s);
+        }
+        if (logz_out) logz_out[n] = logZ;
+
+        /* ---- Log semiring backward (beta) fused with Max semiring backward (bmax); Q = log(P + 1e-8) is kept ---- */
+        for (int i = 0; i < S; ++i) { be[(size_t)T * S + i] = 0.0f; bm[(size_t)T * S + i] = 0.0f; }
+        for (int t = T - 1; t >= 0; --t) {
+            LOADM(t);
+            const float *a0 = al + (size_t)t * S;
+            const float *b1 = be + (size_t)(t + 1) * S;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float *b0 = be + (size_t)t * S;
+            float *m0 = bm + (size_t)t * S;
+            float *qrow = Q + (size_t)t * C;
+            for (int i = 0; i < S; ++i) {
+                /* out-edges of i: stay (j=i,k=0), then new base b: j=(i%hi)*nb+b, k=i/hi+1 */
+                float y[16] = {0};
+                const int kk = i / hi + 1;
+                float mm = -INFINITY;
+                for (int e = 0; e < E; ++e) {
+                    const int j = e == 0 ? i : (i % hi) * nb + e - 1;
+                    const size_t c = (size_t)j * E + (e == 0 ? 0 : kk);
+                    const float mv = M[c];
+                    y[e] = mv + b1[j];
+                    const float xx = ((a0[i] + mv) + b1[j]) - logZ;
+                    const float P = xo_expf_i(xx);
+                    const float q = xo_logf_i(P + 1e-8f);
+                    qrow[c] = q;
+                    if (post_out) post_out[((size_t)t * N + n) * C + c] = P;
+                    const float v = q + m1[j];
+                    mm = v > mm ? v : mm;
+                }
+                b0[i] = xo_lse(y, E);
+                m0[i] = mm;
+            }
+        }
+
+        /* ---- Max semiring forward over Q with per-step arg-max of the max-marginals ---- */
+        float *am0 = am, *am1 = am + S;
+        for (int j = 0; j < S; ++j) am0[j] = 0.0f;
+        if (amax_out) for (int j = 0; j < S; ++j) amax_out[(size_t)n * S + j] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const float *qrow = Q + (size_t)t * C;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float best = -INFINITY;
+            int bestc = 0;
+            for (int j = 0; j < S; ++j) {
+                float mm = -INFINITY;
+                for (int k = 0; k < E; ++k) {
+                    const int src = idx[j * E + k];
+                    const float q = qrow[j * E + k];
+                    const float v = q + am0[src];
+                    mm = v > mm ? v : mm;
+                    const float sc = (am0[src] + q) + m1[j];
+                    if (sc > best) { best = sc; bestc = j * E + k; }
+                }
+                am1[j] = mm;
+            }
+            labels[(size_t)n * T + t] = (int8_t)(bestc % E);
+            if (amax_out) memcpy(amax_out + ((size_t)(t + 1) * N + n) * S, am1, sizeof(float) * (size_t)S);
+            float *tmp = am0; am0 = am1; am1 = tmp;
+        }
+#undef LOADM
+        if (alpha_out) for (int t = 0; t <= T; ++t)
+            memcpy(alpha_out + ((size_t)t * N + n) * S, al + (size_t)t * S, sizeof(float) * (size_t)S);
+        if (beta_out) for (int t = 0; t <= T; ++t)
+            memcpy(beta_out + ((size_t)t * N + n) * S, be + (size_t)t * S, sizeof(float) * (size_t)S);
+        if (qlog_out) for (int t = 0; t < T; ++t)
+            memcpy(qlog_out + ((size_t)t * N + n) * C, Q + (size_t)t * C, sizeof(float) * (size_t)C);
+        if (bmax_out) for (int t = 0; t <= T; ++t)
+            memcpy(bmax_out + ((size_t)t * N + n) * S, bm + (size_t)t * S, sizeof(float) * (size_t)S);
+        free(al); free(be); free(bm); free(M); free(Q); free(am);
+    }
+    free(idx);
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Comparison models for the tie-margin census (tests only; NOT the contract)            */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * (1) xo_decode_scaled: the same sums evaluated on SCALED PROBABILITIES (the classical scaled forward-backward form):
+ *     with w = exp(score),  a_{t+1}[j] = r_t * sum_k w_k a_t[src_k],  r_t an exact power of two that renormalises the
+ *     vector, the integer Ka[t] its running exponent.  In fp32 this is accurate to ~1e-6 against float64, whereas the
+ *     log-domain recursions carry alpha ~ 1e3..1e4 with an ulp of 1e-4..1e-3 -- it stands in for "the exact answer"
+ *     at full-size T where a float64 autograd evaluation is too slow.
+ */
+
+/* exact power of two 2^(bits-127) from a biased exponent field in [1, 254] */
+static inline float xo_pow2_field(int field) { return xo_bits2f((uint32_t)field << 23); }
+
+/* Per-step normaliser of the scaled recursions: the exact power of two r = 2^-(floor(log2 m)) that brings the
+ * largest entry m of the state vector into [1, 2); *shift receives log2(r).  The exponent field of r is clamped to
+ * [1, 254] (only reached by vectors outside the supported score range). */
+static inline float xo_norm_scale(float m, int *shift)
+{
+    const int eb = (int)((xo_f2bits(m) >> 23) & 0xffu);
+    int rf = 254 - eb;
+    if (rf < 1) rf = 1;
+    *shift = rf - 127;
+    return xo_pow2_field(rf);
+}
+
+/*
+ * scores : (T, N, Cin) fp32.  has_blank != 0: Cin = S*E with the stay score in column 0 of
+ *          every state row (LinearCRFEncoder expand_blanks layout, nn.py:123-130).
+ *          has_blank == 0: Cin = S*nb and the stay score is the constant `blank`.
+ * labels : (N, T) int8 out -- argmax % E per time step (0 = no base emitted).
+ * Optional outputs (may be NULL): avec / bvec (T+1,N,S) the scaled forward / backward vectors, aexp / bexp (T+1,N)
+ *          their binary exponents (alpha_t[j] = log(avec) + aexp*ln2), logz (N), post (T,N,S*E) posteriors P,
+ *          qlog (T,N,S*E) = log(P + 1e-8), amax (T+1,N,S), bmax (T+1,N,S).
+ */
+XO_API int xo_decode_scaled(const float *scores, int T, int N, int nb, int sl, int has_blank, float blank,
+                     int8_t *labels, float *avec_out, float *bvec_out, int32_t *aexp_out, int32_t *bexp_out,
+                     float *logz_out, float *post_out, float *qlog_out, float *amax_out, float *bmax_out)
+{
+    const int S = (int)ipow(nb, sl), E = nb + 1, C = S * E;
+    const int Cin = has_blank ? C : S * nb;
+    const int hi = (int)ipow(nb, sl - 1);
+    const int H = (E + 1) / 2;                    /* edges 0..H-1 form the first half-chain, H..E-1 the second */
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)C);
+    if (!idx) return -1;
+    xo_crf_idx(nb, sl, idx);
+    const float wblank = xo_expf_i(blank);
+    int err = 0;
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        const size_t TS = (size_t)(T + 1) * S;
+        float *av = (float *)malloc(sizeof(float) * TS);
+        float *bv = (float *)malloc(sizeof(float) * 2 * (size_t)S);
+        float *bm = (float *)malloc(sizeof(float) * TS);
+        float *W = (float *)malloc(sizeof(float) * (size_t)C);
+        float *Q = (float *)malloc(sizeof(float) * (size_t)T * C);
+        float *am = (float *)malloc(sizeof(float) * 2 * (size_t)S);
+        int32_t *Ka = (int32_t *)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        if (!av || !bv || !bm || !W || !Q || !am || !Ka) {
+            err = -1;
+            free(av); free(bv); free(bm); free(W); free(Q); free(am); free(Ka);
+            continue;
+        }
+        /* edge weights of one time step: w = exp(score), the stay weight in column 0 */
+#define LOADW(t)                                                                                    \
+    do {                                                                                            \
+        const float *row = scores + ((size_t)(t) * N + n) * Cin;                                    \
+        if (has_blank) for (int c_ = 0; c_ < C; ++c_) W[c_] = xo_expf_i(row[c_]);                   \
+        else for (int j_ = 0; j_ < S; ++j_) {                                                       \
+            W[j_ * E] = wblank;                                                                     \
+            for (int k_ = 1; k_ < E; ++k_) W[j_ * E + k_] = xo_expf_i(row[j_ * nb + k_ - 1]);       \
+        }                                                                                           \
+    } while (0)
+
+        /* ---- Log semiring forward, evaluated on scaled probabilities: a_t[j] * 2^Ka[t] = exp(alpha_t[j]) ---- */
+        for (int j = 0; j < S; ++j) av[j] = 1.0f;
+        Ka[0] = 0;
+        for (int t = 0; t < T; ++t) {
+            LOADW(t);
+            const float *a0 = av + (size_t)t * S;
+            float *a1 = av + (size_t)(t + 1) * S;
+            float m = a0[0];
+            for (int j = 1; j < S; ++j) m = a0[j] > m ? a0[j] : m;
+            int shift;
+            const float r = xo_norm_scale(m, &shift);
+            Ka[t + 1] = Ka[t] - shift;
+            for (int j = 0; j < S; ++j) {
+                const float *w = W + (size_t)j * E;
+                const int32_t *src = idx + (size_t)j * E;
+                float p0 = w[0] * a0[src[0]];
+                for (int k = 1; k < H; ++k) p0 = fmaf(w[k], a0[src[k]], p0);
+                float p1 = w[H] * a0[src[H]];
+                for (int k = H + 1; k < E; ++k) p1 = fmaf(w[k], a0[src[k]], p1);
+                a1[j] = (p0 + p1) * r;
+            }
+        }
+        float zs;
+        {
+            const float *aT = av + (size_t)T * S;
+            zs = aT[0];
+            for (int j = 1; j < S; ++j) zs += aT[j];
+        }
+        const float rZ = 1.0f / zs;
+        if (logz_out) logz_out[n] = (float)Ka[T] * 0.693147180559945f + xo_logf_i(zs);
+        if (aexp_out) for (int t = 0; t <= T; ++t) aexp_out[(size_t)t * N + n] = Ka[t];
+
+        /* ---- backward on scaled probabilities (b) fused with the Max semiring backward over Q (bmax) ---- */
+        float *b1 = bv, *b0 = bv + S;
+        for (int i = 0; i < S; ++i) { b1[i] = 1.0f; bm[(size_t)T * S + i] = 0.0f; }
+        int Kb = 0;
+        if (bvec_out) for (int i = 0; i < S; ++i) bvec_out[((size_t)T * N + n) * S + i] = 1.0f;
+        if (bexp_out) bexp_out[(size_t)T * N + n] = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            LOADW(t);
+            const float *a0 = av + (size_t)t * S;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float *m0 = bm + (size_t)t * S;
+            float *qrow = Q + (size_t)t * C;
+            float m = b1[0];
+            for (int i = 1; i < S; ++i) m = b1[i] > m ? b1[i] : m;
+            int shift;
+            const float r = xo_norm_scale(m, &shift);
+            /* P = a_t[i] w b_{t+1}[j] 2^(Ka[t] + Kb[t+1] - Ka[T]) / zs */
+            int kt = Ka[t] + Kb - Ka[T];
+            kt = kt < -126 ? -126 : (kt > 127 ? 127 : kt);
+            const float g = rZ * xo_pow2_field(kt + 127);
+            for (int i = 0; i < S; ++i) {
+                /* out-edges of i: stay (j=i,k=0), then new base b: j=(i%hi)*nb+b, k=i/hi+1 */
+                float we[16], be[16];
+                int dst[16], col[16];
+                const int kk = i / hi + 1;
+                dst[0] = i; col[0] = 0;
+                for (int b = 0; b < nb; ++b) { dst[b + 1] = (i % hi) * nb + b; col[b + 1] = kk; }
+                for (int e = 0; e < E; ++e) { we[e] = W[dst[e] * E + col[e]]; be[e] = b1[dst[e]]; }
+                float q0 = we[0] * be[0];
+                for (int e = 1; e < H; ++e) q0 = fmaf(we[e], be[e], q0);
+                float q1 = we[H] * be[H];
+                for (int e = H + 1; e < E; ++e) q1 = fmaf(we[e], be[e], q1);
+                b0[i] = (q0 + q1) * r;
+                float mm = -INFINITY;
+                for (int e = 0; e < E; ++e) {
+                    const float P = ((a0[i] * we[e]) * be[e]) * g;
+                    const float q = xo_logf_i(P + 1e-8f);
+                    const size_t c = (size_t)dst[e] * E + col[e];
+                    qrow[c] = q;
+                    if (post_out) post_out[((size_t)t * N + n) * C + c] = P;
+                    const float v = q + m1[dst[e]];
+                    mm = v > mm ? v : mm;
+                }
+                m0[i] = mm;
+            }
+            Kb -= shift;
+            if (bvec_out) memcpy(bvec_out + ((size_t)t * N + n) * S, b0, sizeof(float) * (size_t)S);
+            if (bexp_out) bexp_out[(size_t)t * N + n] = Kb;
+            float *tmp = b0; b0 = b1; b1 = tmp;
+        }
+
+        /* ---- Max semiring forward over Q with per-step arg-max of the max-marginals ---- */
+        float *am0 = am, *am1 = am + S;
+        for (int j = 0; j < S; ++j) am0[j] = 0.0f;
+        if (amax_out) for (int j = 0; j < S; ++j) amax_out[(size_t)n * S + j] = 0.0f;
+        for (int t = 0; t < T; ++t) {
+            const float *qrow = Q + (size_t)t * C;
+            const float *m1 = bm + (size_t)(t + 1) * S;
+            float best = -INFINITY;
+            int bestc = 0;
+            for (int j = 0; j < S; ++j) {
+                float mm = -INFINITY;
+                for (int k = 0; k < E; ++k) {
+                    const int src = idx[j * E + k];
+                    const float q = qrow[j * E + k];
+                    const float v = q + am0[src];
+                    mm = v > mm ? v : mm;
+                    const float sc = (am0[src] + q) + m1[j];
+                    if (sc > best) { best = sc; bestc = j * E + k; }
+                }
+                am1[j] = mm;
+            }
+            labels[(size_t)n * T + t] = (int8_t)(bestc % E);
+            if (amax_out) memcpy(amax_out + ((size_t)(t + 1) * N + n) * S, am1, sizeof(float) * (size_t)S);
+            float *tmp = am0; am0 = am1; am1 = tmp;
+        }
+#undef LOADW
+        if (avec_out) for (int t = 0; t <= T; ++t)
+            memcpy(avec_out + ((size_t)t * N + n) * S, av + (size_t)t * S, sizeof(float) * (size_t)S);
+        if (qlog_out) for (int t = 0; t < T; ++t)
+            memcpy(qlog_out + ((size_t)t * N + n) * C, Q + (size_t)t * C, sizeof(float) * (size_t)C);
+        if (bmax_out) for (int t = 0; t <= T; ++t)
+            memcpy(bmax_out + ((size_t)t * N + n) * S, bm + (size_t)t * S, sizeof(float) * (size_t)S);
+        free(av); free(bv); free(bm); free(W); free(Q); free(am); free(Ka);
+    }
+    free(idx);
+    return err;
+}
+
+/*
+ * (2) xo_decode_logdomain: the decode evaluated the way a straightforward log-domain fp32 implementation (such as seqdist's
+ * CUDA kernels) would: alpha/beta by logsumexp (max, ordered sum of exp, log), posteriors
+ * P = exp(alpha + M + beta - logZ), Q = log(P + 1e-8), then the Max-semiring passes.
+ * math: 0 = the polynomial xo_expf/xo_logf, 1 = libm expf/logf, 2 = libm with the posteriors normalised per time
+ * step by a softmax over all edges, P = exp(x - max x) / sum exp(x - max x) with x = (M + alpha[src]) + beta[dst]
+ * (the form seqdist's Log.dsum takes) instead of exp(x - logZ).
+ * gap (N,T) optional: max-marginal of the winning edge minus the best max-marginal among edges with a
+ * DIFFERENT label (the margin a differently rounded implementation would have to overcome to flip the call).
+ */
+static inline float cm_exp(float x, int math) { return math ? expf(x) : xo_expf_i(x); }
+static inline float cm_log(float x, int math) { return math ? logf(x) : xo_logf_i(x); }
+/* max and sum of exp(x - max) over all edges of one time step, x = (M + alpha[src]) + beta[dst] */
+static void cm_softmax_norm(const float *M, const float *a0, const float *b1, const int32_t *idx, int S, int E,
+                            float *mx, float *sum)
+{
+    float m = -INFINITY;
+    for (int j = 0; j < S; ++j)
+        for (int k = 0; k < E; ++k) {
+            const float x = (M[j * E + k] + a0[idx[j * E + k]]) + b1[j];
+            m = x > m ? x : m;
+        }
+    float s = 0.0f;
+    for (int j = 0; j < S; ++j)
+        for (int k = 0; k < E; ++k) s += expf(((M[j * E + k] + a0[idx[j * E + k]]) + b1[j]) - m);
+    *mx = m;
+    *sum = s;
+}
+
+XO_API int xo_decode_logdomain(const float *scores, int T, int N, int nb, int sl, int has_blank, float blank,
+                               int math, int8_t *labels, float *gap_out, float *logz_out, float *post_out)
 {
     const int S = (int)ipow(nb, sl), E = nb + 1, C = S * E;
     const int Cin = has_blank ? C : S * nb;
@@ -178,8 +558,6 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
             for (int k_ = 1; k_ < E; ++k_) M[j_ * E + k_] = row[j_ * nb + k_ - 1];                  \
         }                                                                                           \
     } while (0)
-
-        /* ---- Log semiring forward: alpha ---- */
         for (int j = 0; j < S; ++j) al[j] = 0.0f;
         for (int t = 0; t < T; ++t) {
             LOADM(t);
@@ -192,9 +570,9 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
                     x[k] = M[j * E + k] + a0[idx[j * E + k]];
                     m = x[k] > m ? x[k] : m;
                 }
-                float s = xo_expf_i(x[0] - m);
-                for (int k = 1; k < E; ++k) s += xo_expf_i(x[k] - m);
-                a1[j] = m + xo_logf_i(s);
+                float s = cm_exp(x[0] - m, math);
+                for (int k = 1; k < E; ++k) s += cm_exp(x[k] - m, math);
+                a1[j] = m + cm_log(s, math);
             }
         }
         float logZ;
@@ -202,13 +580,11 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
             const float *aT = al + (size_t)T * S;
             float m = -INFINITY;
             for (int j = 0; j < S; ++j) m = aT[j] > m ? aT[j] : m;
-            float s = xo_expf_i(aT[0] - m);
-            for (int j = 1; j < S; ++j) s += xo_expf_i(aT[j] - m);
-            logZ = m + xo_logf_i(s);
+            float s = cm_exp(aT[0] - m, math);
+            for (int j = 1; j < S; ++j) s += cm_exp(aT[j] - m, math);
+            logZ = m + cm_log(s, math);
         }
         if (logz_out) logz_out[n] = logZ;
-
-        /* ---- Log semiring backward (beta) fused with Max semiring backward (bmax) ---- */
         for (int i = 0; i < S; ++i) { be[(size_t)T * S + i] = 0.0f; bm[(size_t)T * S + i] = 0.0f; }
         for (int t = T - 1; t >= 0; --t) {
             LOADM(t);
@@ -217,8 +593,9 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
             const float *m1 = bm + (size_t)(t + 1) * S;
             float *b0 = be + (size_t)t * S;
             float *m0 = bm + (size_t)t * S;
+            float smx = 0.0f, ssum = 1.0f;
+            if (math == 2) cm_softmax_norm(M, a0, b1, idx, S, E, &smx, &ssum);
             for (int i = 0; i < S; ++i) {
-                /* out-edges of i: stay (j=i,k=0), then new base b: j=(i%hi)*nb+b, k=i/hi+1 */
                 float y[16], q[16];
                 int dst[16];
                 const int kk = i / hi + 1;
@@ -230,14 +607,14 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
                     const float mv = M[j * E + (e == 0 ? 0 : kk)];
                     y[e] = mv + b1[j];
                     m = y[e] > m ? y[e] : m;
-                    const float xx = ((a0[i] + mv) + b1[j]) - logZ;
-                    const float P = xo_expf_i(xx);
-                    q[e] = xo_logf_i(P + 1e-8f);
+                    const float P = math == 2 ? cm_exp(((mv + a0[i]) + b1[j]) - smx, 1) / ssum
+                                              : cm_exp(((a0[i] + mv) + b1[j]) - logZ, math);
+                    q[e] = cm_log(P + 1e-8f, math);
                     if (post_out) post_out[((size_t)t * N + n) * C + (size_t)j * E + (e == 0 ? 0 : kk)] = P;
                 }
-                float s = xo_expf_i(y[0] - m);
-                for (int e = 1; e < E; ++e) s += xo_expf_i(y[e] - m);
-                b0[i] = m + xo_logf_i(s);
+                float s = cm_exp(y[0] - m, math);
+                for (int e = 1; e < E; ++e) s += cm_exp(y[e] - m, math);
+                b0[i] = m + cm_log(s, math);
                 float mm = q[0] + m1[dst[0]];
                 for (int e = 1; e < E; ++e) {
                     const float v = q[e] + m1[dst[e]];
@@ -246,42 +623,43 @@ XO_API int xo_decode(const float *scores, int T, int N, int nb, int sl, int has_
                 m0[i] = mm;
             }
         }
-
-        /* ---- Max semiring forward with per-step arg-max of the max-marginals ---- */
         float *am0 = am, *am1 = am + S;
         for (int j = 0; j < S; ++j) am0[j] = 0.0f;
-        if (amax_out) for (int j = 0; j < S; ++j) amax_out[(size_t)n * S + j] = 0.0f;
         for (int t = 0; t < T; ++t) {
             LOADM(t);
             const float *a0 = al + (size_t)t * S;
             const float *b1 = be + (size_t)(t + 1) * S;
             const float *m1 = bm + (size_t)(t + 1) * S;
+            float bestk[16];
+            for (int k = 0; k < E; ++k) bestk[k] = -INFINITY;
+            float smx = 0.0f, ssum = 1.0f;
+            if (math == 2) cm_softmax_norm(M, a0, b1, idx, S, E, &smx, &ssum);
             float best = -INFINITY;
             int bestc = 0;
             for (int j = 0; j < S; ++j) {
                 float mm = -INFINITY;
                 for (int k = 0; k < E; ++k) {
                     const int src = idx[j * E + k];
-                    const float xx = ((a0[src] + M[j * E + k]) + b1[j]) - logZ;
-                    const float Q = xo_logf_i(xo_expf_i(xx) + 1e-8f);
-                    const float v = Q + am0[src];
+                    const float Pv = math == 2 ? cm_exp(((M[j * E + k] + a0[src]) + b1[j]) - smx, 1) / ssum
+                                               : cm_exp(((a0[src] + M[j * E + k]) + b1[j]) - logZ, math);
+                    const float Qv = cm_log(Pv + 1e-8f, math);
+                    const float v = Qv + am0[src];
                     mm = v > mm ? v : mm;
-                    const float sc = (am0[src] + Q) + m1[j];
+                    const float sc = (am0[src] + Qv) + m1[j];
                     if (sc > best) { best = sc; bestc = j * E + k; }
+                    if (sc > bestk[k]) bestk[k] = sc;
                 }
                 am1[j] = mm;
             }
             labels[(size_t)n * T + t] = (int8_t)(bestc % E);
-            if (amax_out) memcpy(amax_out + ((size_t)(t + 1) * N + n) * S, am1, sizeof(float) * (size_t)S);
+            if (gap_out) {
+                float second = -INFINITY;
+                for (int k = 0; k < E; ++k) if (k != bestc % E && bestk[k] > second) second = bestk[k];
+                gap_out[(size_t)n * T + t] = best - second;
+            }
             float *tmp = am0; am0 = am1; am1 = tmp;
         }
 #undef LOADM
-        if (alpha_out) for (int t = 0; t <= T; ++t)
-            memcpy(alpha_out + ((size_t)t * N + n) * S, al + (size_t)t * S, sizeof(float) * (size_t)S);
-        if (beta_out) for (int t = 0; t <= T; ++t)
-            memcpy(beta_out + ((size_t)t * N + n) * S, be + (size_t)t * S, sizeof(float) * (size_t)S);
-        if (bmax_out) for (int t = 0; t <= T; ++t)
-            memcpy(bmax_out + ((size_t)t * N + n) * S, bm + (size_t)t * S, sizeof(float) * (size_t)S);
         free(al); free(be); free(bm); free(M); free(am);
     }
     free(idx);

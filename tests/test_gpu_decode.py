@@ -28,12 +28,10 @@ def _check(ctx, sc, nb, alphabet, sl=3, blank=None):
 
 @pytest.mark.parametrize("nb", [4, 5, 6])
 @pytest.mark.parametrize("with_blank", [True, False])
-@pytest.mark.parametrize("lps", [0, 1, 2, 4])
+@pytest.mark.parametrize("lps", [0, 1, 2])
 def test_decode_bit_exact_random(nb, with_blank, lps, monkeypatch):
     """lps = lanes per CRF state (0: the library's own choice); every variant must give the same bits."""
     if lps:
-        if lps * nb ** 3 > 512:
-            pytest.skip("block would exceed 512 threads")
         monkeypatch.setenv("XB_DECODE_LPS", str(lps))
     alphabet = "NACGTXY"[:nb + 1]
     T, N = 203, 5                                   # T not a multiple of the prefetch depth
@@ -87,7 +85,7 @@ def test_decode_full_length_chunks():
     ctx.close()
 
 
-@pytest.mark.parametrize("lps", [1, 2, 4])
+@pytest.mark.parametrize("lps", [1, 2])
 def test_decode_full_length_odd_stride(lps, monkeypatch):
     """T = 2000 with the 5-base CRF and no blank column: row stride 625 floats (4-byte loads, deepest register
     ring) -- the configuration that exposed reuse of a prefetch register behind an unconsumed load."""

@@ -15,7 +15,9 @@ def test_spec_math_accuracy():
     e = oracle.expf(x)
     ref = np.exp(x.astype(np.float64))
     assert np.max(np.abs(e - ref) / ref) < 2e-7
-    assert oracle.expf(np.array([-88.0, -1e38, -np.inf], np.float32)).tolist() == [0.0, 0.0, 0.0]
+    # the argument is clamped to [-87, 88]: anything smaller evaluates as exp(-87) = 1.6e-38 (no flush to zero)
+    tiny = oracle.expf(np.array([-87.0, -88.0, -1e38, -np.inf], np.float32))
+    assert np.all(tiny == tiny[0]) and 1e-38 < tiny[0] < 2e-38
     x = np.exp(np.linspace(np.log(1e-8), np.log(8), 100001)).astype(np.float32)
     l = oracle.logf(x)
     assert np.max(np.abs(l - np.log(x.astype(np.float64)))) < 2e-6
@@ -70,14 +72,42 @@ def _backpointer_viterbi(Q, idx):
 def test_decode_against_float64_restatement(nb):
     sl, T, N = 3, 64, 3
     sc = random_scores(T, N, nb, sl, seed=nb)
-    out = oracle.decode(sc, nb, sl, want=("logz", "post", "alpha", "beta"))
+    out = oracle.decode(sc, nb, sl, want=("logz", "post", "alpha", "beta", "qlog"))
     P, logZ = _fp64_posteriors(sc, nb, sl)
     assert np.abs(out["logz"] - logZ).max() < 1e-3
     assert np.abs(out["post"] - P).max() < 1e-4
     assert np.abs(out["post"].sum(2) - 1).max() < 1e-3
     assert np.all(out["alpha"][0] == 0) and np.all(out["beta"][-1] == 0)
+    assert np.abs(out["qlog"] - np.log(out["post"].astype(np.float64) + 1e-8)).max() < 2e-6
     lab = _backpointer_viterbi(np.log(P + 1e-8).reshape(T, N, nb ** sl, nb + 1), oracle.crf_idx(nb, sl))
     assert np.array_equal(lab, out["labels"])
+
+
+def test_scaled_comparison_model_is_float64_grade():
+    """oracle.decode_scaled (census comparison model, not the contract): a_t * 2^Ka[t] = exp(alpha_t) of the float64
+    logsumexp recursions (crf/model.py:41-46 semantics), and posteriors at fp32 rounding level."""
+    import torch
+    nb, sl, T, N = 5, 3, 400, 2
+    sc = random_scores(T, N, nb, sl, seed=77)
+    out = oracle.decode_scaled(sc, nb, sl, want=("avec", "aexp", "post", "logz"))
+    S, E = nb ** sl, nb + 1
+    idx = torch.from_numpy(oracle.crf_idx(nb, sl)).long()
+    Ms = torch.tensor(sc, dtype=torch.float64).reshape(T, N, S, E)
+    a = torch.zeros(N, S, dtype=torch.float64)
+    alphas = [a]
+    for t in range(T):
+        a = torch.logsumexp(Ms[t] + a[:, idx], dim=2)
+        alphas.append(a)
+    alpha = torch.stack(alphas).numpy()
+    got = np.log(out["avec"].astype(np.float64)) + out["aexp"][:, :, None] * np.log(2.0)
+    assert np.abs(got - alpha).max() < 1e-4
+    assert abs(out["aexp"][-1]).min() > 100          # the exponent bookkeeping is exercised
+    P, logZ = _fp64_posteriors(sc[:64], nb, sl)
+    out = oracle.decode_scaled(sc[:64], nb, sl, want=("post",))
+    assert np.abs(out["post"] - P).max() < 2e-6
+    assert np.abs(out["post"].sum(2) - 1).max() < 1e-5
+    # and the contract (log domain) calls the same labels on this easy case
+    assert np.array_equal(oracle.decode(sc, nb, sl)["labels"], oracle.decode_scaled(sc, nb, sl)["labels"])
 
 
 def test_decode_blank_column_equivalence():

@@ -6,25 +6,39 @@
 //   (crf/model.py:92-95), then path_to_str (crf/model.py:97-100) and the left-pack of
 //   compute_scores (crf/basecall.py:60-67).
 //
-// One workgroup per chunk, one thread per CRF state; the state vectors (alpha, beta, max-plus
-// alpha/beta) live in LDS and are exchanged once per time step behind a single barrier.
-// Scores stream from HBM through a register ring (D steps ahead) in 4/8/16-byte coalesced
-// loads, are staged in LDS and consumed by state.  Three sweeps over the scores:
+// One workgroup per chunk; a CRF state is served by LPS = 1 or 2 adjacent lanes that split its E = nb+1 edges in
+// two halves.  The state vectors (alpha, beta, max-plus alpha/beta) live in LDS and are exchanged once per time step
+// behind a single LDS-only barrier.  Three sweeps over the scores:
 //   1. Log forward           (write alpha)
-//   2. Log backward fused with Max backward (read alpha; write beta, bmax) -- also writes the
-//      log-posteriors Q = log(P + 1e-8) of every edge, (T, N, S*E) fp32, staged by destination
-//      edge in LDS and stored as coalesced rows one step late
+//   2. Log backward fused with Max backward (read alpha; write bmax) -- also writes the log-posteriors
+//      Q = log(P + 1e-8) of every edge, (T, N, S*E) fp32, scattered by destination edge into an LDS row and stored as
+//      coalesced rows one step late
 //   3. Max forward over Q + per-step arg-max of the max-marginals (read Q, bmax), then pack.
-// (Storing Q trades C*4 extra bytes per step for not recomputing 2*E transcendentals per state
-//  in sweep 3, which then is as light as sweep 1; the values are the same floats either way.)
 //
-// Floating-point contract (shared by specification with oracle/xna_oracle.c, written
-// independently): IEEE binary32, no contraction (this file is built with -ffp-contract=off),
-// fma only where __builtin_fmaf is written, exp/log are the fixed polynomials below, logsumexp
-// is max / ordered sum of exp / log, ties resolve to the lowest flat edge index.
+// What bounds a step is the LENGTH OF ITS DEPENDENCY CHAIN, not bytes or instruction count (a dependent VALU
+// instruction issues every ~8 cycles, independent ones every ~2.4 per SIMD: tools/valu_probe.hip), so the kernel is
+// built to keep the chain short:
+//   * sweeps 1 and 3 are "destination owned": a lane's score / Q values are E (or E/2) CONTIGUOUS floats of the row,
+//     loaded straight into a register ring RDEPTH steps ahead (no LDS staging); the state vector is kept in LDS in a
+//     transposed order, position (i % hi) * nb + i / hi, so that the nb source states of a destination are contiguous;
+//     a state's own previous value (the stay edge) never leaves its registers;
+//   * sweep 2 is "source owned"; its strided score reads go through an LDS-staged row, and the state -> lane map is
+//     permuted (lane group = nb sources that share their destinations) so that those reads are at most 2-way conflicted;
+//   * reductions use v_max_f32_dpp / v_add_f32_dpp directly (hipcc emits v_mov_b32_dpp + a separate op + s_nops for the
+//     update_dpp builtin); the per-step arg-max is a wave max + ballot (lane order == flat edge order, so the lowest
+//     matching lane IS the lowest flat index), per-wave partials go to a 128-step LDS ring and are finalised 64 steps
+//     at a time, one step per lane;
+//   * the log polynomial is evaluated in Estrin form (depth 4 instead of 8).
+//
+// Floating-point contract (shared by specification with oracle/xna_oracle.c, written independently): IEEE binary32,
+// no contraction (this file is built with -ffp-contract=off), fma only where __builtin_fmaf is written, exp/log are the
+// fixed polynomials below, logsumexp = max / exps summed in edge order / log, ties resolve to the lowest
+// flat edge index.  The recursions stay in the log domain on purpose (see the oracle's header).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "xb_internal.h"
 
@@ -35,9 +49,7 @@ __device__ __forceinline__ uint32_t f2bits(float f) { return __builtin_bit_cast(
 
 __device__ __forceinline__ float xb_expf(float x)
 {
-    const bool tiny = x < -87.0f;
-    x = x > 88.0f ? 88.0f : x;
-    x = tiny ? 0.0f : x;
+    x = __builtin_amdgcn_fmed3f(x, -87.0f, 88.0f);              // clamp (one instruction), no flush to zero
     const float n = __builtin_rintf(x * 1.44269504088896341f);
     float r = __builtin_fmaf(n, -0.693359375f, x);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
@@ -51,8 +63,7 @@ __device__ __forceinline__ float xb_expf(float x)
     const float y = __builtin_fmaf(p, r2, r) + 1.0f;
     const int ni = (int)n;
     const float s = bits2f((uint32_t)(ni + 127) << 23);
-    const float v = y * s;
-    return tiny ? 0.0f : v;
+    return y * s;
 }
 
 __device__ __forceinline__ float xb_logf(float x)
@@ -65,15 +76,16 @@ __device__ __forceinline__ float xb_logf(float x)
     e = big ? e + 1 : e;
     const float f = m - 1.0f;
     const float z = f * f;
-    float p = 7.0376836292e-2f;
-    p = __builtin_fmaf(p, f, -1.1514610310e-1f);
-    p = __builtin_fmaf(p, f, 1.1676998740e-1f);
-    p = __builtin_fmaf(p, f, -1.2420140846e-1f);
-    p = __builtin_fmaf(p, f, 1.4249322787e-1f);
-    p = __builtin_fmaf(p, f, -1.6668057665e-1f);
-    p = __builtin_fmaf(p, f, 2.0000714765e-1f);
-    p = __builtin_fmaf(p, f, -2.4999993993e-1f);
-    p = __builtin_fmaf(p, f, 3.3333331174e-1f);
+    const float z2 = z * z;
+    const float z4 = z2 * z2;
+    const float q01 = __builtin_fmaf(-2.4999993993e-1f, f, 3.3333331174e-1f);
+    const float q23 = __builtin_fmaf(-1.6668057665e-1f, f, 2.0000714765e-1f);
+    const float q45 = __builtin_fmaf(-1.2420140846e-1f, f, 1.4249322787e-1f);
+    const float q67 = __builtin_fmaf(-1.1514610310e-1f, f, 1.1676998740e-1f);
+    const float q03 = __builtin_fmaf(q23, z, q01);
+    const float q47 = __builtin_fmaf(q67, z, q45);
+    const float q07 = __builtin_fmaf(q47, z2, q03);
+    const float p = __builtin_fmaf(7.0376836292e-2f, z4, q07);
     float y = (f * z) * p;
     const float fe = (float)e;
     y = __builtin_fmaf(fe, -2.12194440e-4f, y);
@@ -86,7 +98,7 @@ __device__ __forceinline__ float xb_logf(float x)
 __device__ __forceinline__ float maxf(float a, float b) { return b > a ? b : a; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. emits
-// s_waitcnt vmcnt(0), which would drain the score prefetch ring (a full HBM latency) at every time step.
+// s_waitcnt vmcnt(0), which would drain the prefetch ring (a full HBM latency) at every time step.
 // Inside the sweeps the only cross-thread data is in LDS; the global stashes are re-read by the thread that
 // wrote them (and the sweeps are separated by real __syncthreads()).
 __device__ __forceinline__ void lds_barrier()
@@ -94,206 +106,280 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int VW> struct VecT;
-template <> struct VecT<1> { using type = float; };
-// native clang vectors (HIP's float2/float4 wrapper structs defeat scalar replacement in arrays)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <> struct VecT<2> { using type = f32x2; };
-template <> struct VecT<4> { using type = f32x4; };
+// ---- cross-lane arithmetic on DPP, one instruction per step ---------------------------------------------------
+// (2 wait states between a VALU write of a register and a DPP read of it: the s_nop 1 in front of every step)
+// max over the 64 lanes, valid in lane 63; lanes without a DPP source keep their own value
+__device__ __forceinline__ float wave_max63(float v)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+// max / sum with the partner lane of a pair (lanes 2s, 2s+1): both lanes receive the result
+__device__ __forceinline__ float pair_max(float v)
+{
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(v));
+    return v;
+}
+// Sum, in edge order 0..E-1, of the E values a lane pair holds (lane 0: edges [0, H) in ex[0..], lane 1: edges [H, E)):
+// every term is fetched from the lane that holds it by a fused broadcast-add, so both lanes run the identical chain
+// e_0, + e_1, .. + e_{E-1}.  ONE asm statement: all ex[] are inputs, i.e. written before it starts (the leading s_nop
+// covers the VALU-write -> DPP-read wait states of the last one); inside, only `s` is written and it is never DPP-read.
+#define XB_BC0 "quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+#define XB_BC1 "quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+template <int E>
+__device__ __forceinline__ float pair_sum_ordered(const float (&ex)[(E + 1) / 2])
+{
+    float s;
+    static_assert(E >= 5 && E <= 7, "pair_sum_ordered is written out for 4, 5 and 6 bases");
+    if constexpr (E == 5)
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %0, %1 " XB_BC0 "v_add_f32_dpp %0, %2, %0 " XB_BC0 "v_add_f32_dpp %0, %3, %0 " XB_BC0
+                     "v_add_f32_dpp %0, %1, %0 " XB_BC1 "v_add_f32_dpp %0, %2, %0 " XB_BC1 "s_nop 0"
+                     : "=&v"(s) : "v"(ex[0]), "v"(ex[1]), "v"(ex[2]));
+    else if constexpr (E == 6)
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %0, %1 " XB_BC0 "v_add_f32_dpp %0, %2, %0 " XB_BC0 "v_add_f32_dpp %0, %3, %0 " XB_BC0
+                     "v_add_f32_dpp %0, %1, %0 " XB_BC1 "v_add_f32_dpp %0, %2, %0 " XB_BC1 "v_add_f32_dpp %0, %3, %0 " XB_BC1 "s_nop 0"
+                     : "=&v"(s) : "v"(ex[0]), "v"(ex[1]), "v"(ex[2]));
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_mov_b32_dpp %0, %1 " XB_BC0 "v_add_f32_dpp %0, %2, %0 " XB_BC0 "v_add_f32_dpp %0, %3, %0 " XB_BC0
+                     "v_add_f32_dpp %0, %4, %0 " XB_BC0
+                     "v_add_f32_dpp %0, %1, %0 " XB_BC1 "v_add_f32_dpp %0, %2, %0 " XB_BC1 "v_add_f32_dpp %0, %3, %0 " XB_BC1 "s_nop 0"
+                     : "=&v"(s) : "v"(ex[0]), "v"(ex[1]), "v"(ex[2]), "v"(ex[3]));
+    return s;
+}
+#undef XB_BC0
+#undef XB_BC1
 
-// ---- prefetch: register ring with PLAIN (compiler-visible) loads -------------------------------------------
-// Score / Q rows of the next RDEPTH steps are held in registers and staged through LDS once per step.  The loads
-// are ordinary loads, fully tracked by hipcc: nothing can be copied or reused while in flight.  (An inline-asm
-// load ring with hand-counted s_waitcnt was faster by ~8 % but NOT safe: hipcc may re-allocate or copy an asm
-// load's destination before the data arrives, and an issued-but-unconsumed load corrupts whatever reuses its
-// register; an LDS-DMA ring is safe but ~25 % slower, each DMA instruction stalls its wave for 60-185 cycles.)
-// The memory part of every sweep is branch-free -- loops run over T rounded up to RDEPTH with clamped
-// addresses, LDS staging is unconditional (padded buffers), only the arithmetic is guarded -- which is what
-// lets the compiler's own s_waitcnt insertion count the in-order loads (vmcnt(9..12)) instead of draining them.
-template <int VW, int NR, int BS>
+// CNT consecutive floats from a 4-byte aligned address in the widest pieces (global_load_dwordx4 / x2 / dword)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int CNT>
+__device__ __forceinline__ void load_seg(const float *p, float (&r)[CNT])
+{
+    int o = 0;
+    if constexpr (CNT >= 4) {
+        const f32x4u v = *reinterpret_cast<const f32x4u *>(p);
+        r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
+        o = 4;
+    }
+    if constexpr ((CNT & 3) >= 2) {
+        const f32x2u v = *reinterpret_cast<const f32x2u *>(p + (CNT & ~3));
+        r[(CNT & ~3)] = v[0]; r[(CNT & ~3) + 1] = v[1];
+        o = (CNT & ~3) + 2;
+    }
+    if constexpr (CNT & 1) r[CNT - 1] = p[CNT - 1];
+    (void)o;
+}
+
+constexpr int RDEPTH = 8;     // register-ring depth (time steps in flight)
+constexpr int LRING = 128;    // arg-max partial ring (steps); finalised 64 at a time
+
+// coalesced row staging for sweep 2: NR 16-byte groups per thread, loaded RDEPTH steps ahead, written to LDS per step
+template <int NR, int BS>
 struct RowRegs {
-    using V = typename VecT<VW>::type;
-    V r[NR];
+    f32x4 r[NR];
     __device__ __forceinline__ void load(const float *row, int lim, int tid)
     {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int g = (tid + BS * i) * VW;
-            r[i] = *reinterpret_cast<const V *>(row + (g < lim ? g : 0));
+            const int g = (tid + BS * i) * 4;
+            r[i] = *reinterpret_cast<const f32x4 *>(row + (g < lim ? g : 0));
         }
     }
     __device__ __forceinline__ void store(float *lds, int tid) const
     {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) *reinterpret_cast<V *>(lds + (tid + BS * i) * VW) = r[i];
+        for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4 *>(lds + (tid + BS * i) * 4) = r[i];
     }
 };
-constexpr int RDEPTH = 4;  // register-ring depth (steps in flight)
-
-
-// wave64 arg-max of (value, flat index), ties to the lowest index, on DPP row shifts / row broadcasts
-// (no LDS round trips).  The result is valid in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void argmax_dpp_step(float &v, int &c)
-{
-    // lanes without a source keep `old` = the identity (-inf, INT_MAX)
-    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-        (int)0xff800000, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-    const int oc = __builtin_amdgcn_update_dpp(0x7fffffff, c, CTRL, ROW_MASK, 0xf, false);
-    if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; }
-}
-// ---- lane clusters: a state is served by LPS = 1, 2 or 4 adjacent lanes (inside one DPP quad) --------------
-template <int CTRL> __device__ __forceinline__ float quad_perm(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-// max over the LPS lanes of a cluster (max is exact: any order)
-template <int LPS> __device__ __forceinline__ float cluster_max(float v)
-{
-    if (LPS >= 2) { const float o = quad_perm<0xB1>(v); v = o > v ? o : v; }    // quad_perm [1,0,3,2]
-    if (LPS >= 4) { const float o = quad_perm<0x4E>(v); v = o > v ? o : v; }    // quad_perm [2,3,0,1]
-    return v;
-}
-// value held by lane P of this lane's cluster
-template <int LPS, int P> __device__ __forceinline__ float cluster_get(float v)
-{
-    if (LPS == 1) return v;
-    if (LPS == 2) return quad_perm<(P) | (P << 2) | ((2 + P) << 4) | ((2 + P) << 6)>(v);   // pairs {0,1} {2,3}
-    return quad_perm<(P & 3) | ((P & 3) << 2) | ((P & 3) << 4) | ((P & 3) << 6)>(v);
-}
-// Ordered sum over the E terms of a cluster: lane p holds terms e = p*EPER + r in x[r]; every lane of the cluster
-// accumulates all terms in edge order e = 0..E-1 (the contract's summation order), fetching them by DPP.
-template <int LPS, int E, int EPER, int PP = 0, int R = 0>
-__device__ __forceinline__ void ordered_sum(const float (&x)[EPER], float &s)
-{
-    if constexpr (PP < LPS) {
-        if constexpr (PP * EPER + R < E) {
-            const float v = cluster_get<LPS, PP>(x[R]);
-            s = (PP == 0 && R == 0) ? v : s + v;
+// the same with 4-byte loads for rows that are not 16-byte aligned (scores handed in with an odd row length)
+template <int NR, int BS>
+struct RowRegs1 {
+    float r[NR];
+    __device__ __forceinline__ void load(const float *row, int lim, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int g = tid + BS * i;
+            r[i] = row[g < lim ? g : 0];
         }
-        if constexpr (R + 1 < EPER) ordered_sum<LPS, E, EPER, PP, R + 1>(x, s);
-        else ordered_sum<LPS, E, EPER, PP + 1, 0>(x, s);
     }
-}
-__device__ __forceinline__ void wave_argmax(float &v, int &c)
-{
-    argmax_dpp_step<0x111, 0xf>(v, c);   // row_shr:1
-    argmax_dpp_step<0x112, 0xf>(v, c);   // row_shr:2
-    argmax_dpp_step<0x114, 0xf>(v, c);   // row_shr:4
-    argmax_dpp_step<0x118, 0xf>(v, c);   // row_shr:8   -> lane 15 of every row holds the row result
-    argmax_dpp_step<0x142, 0xa>(v, c);   // row_bcast:15 into rows 1 and 3
-    argmax_dpp_step<0x143, 0xc>(v, c);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave result
-}
+    __device__ __forceinline__ void store(float *lds, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) lds[tid + BS * i] = r[i];
+    }
+};
 
-// M[j][k] from the staged row: with the blank column present it is lds[j*E+k]; otherwise column 0
-// is the constant blank and column k>=1 is lds[j*NB + k-1].
-template <int NB, bool HB>
-__device__ __forceinline__ float score_at(const float *lds, int j, int k, float blank)
-{
-    constexpr int E = NB + 1;
-    if (HB) return lds[j * E + k];
-    return k == 0 ? blank : lds[j * NB + k - 1];
-}
+// Edge bookkeeping of a lane.  A state's E edges are split in two halves [0, H) and [H, E), H = ceil(E/2).
+// LPS == 1: the lane owns all E edges (local index r = edge).  LPS == 2: lane `ph` of the pair owns half `ph`
+// (local index r = edge - ph * H; the second half has E - H <= H edges, its last local index may be invalid).
+template <int E, int LPS>
+struct Edges {
+    static constexpr int H = (E + 1) / 2;
+    static constexpr int EPER = LPS == 1 ? E : H;
+};
 
-// LPS = lanes per state (1, 2 or 4): the E edges of a state are split in blocks of EPER over LPS adjacent lanes;
-// the block has BS >= LPS*S threads.
-template <int NB, int BS, int VW, bool HB, int LPS>
+// NB bases, BS threads (multiple of 64, >= LPS * S), HB: the scores carry the blank column, LPS lanes per state,
+// VW: 4 = 16-byte staging loads in sweep 2 (row stride and base 16-byte aligned), 1 = 4-byte loads
+template <int NB, int BS, bool HB, int LPS, int VW>
 __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 {
     constexpr int E = NB + 1;
+    constexpr int H = Edges<E, LPS>::H;
+    constexpr int EPER = Edges<E, LPS>::EPER;
     constexpr int NW = BS / 64;
-    constexpr int EPER = (E + LPS - 1) / LPS;    // edges per lane
+    // Score columns a lane loads per row in sweep 1.  With the blank column: its EPER edge columns (the second lane of a
+    // pair loads the LAST EPER columns of the state so that it never reads past the row).  Without it: all NB columns
+    // (LPS 1), or E - H columns (LPS 2: first lane columns 0.., second lane columns H-1..).
+    constexpr int CPL = HB ? EPER : (LPS == 1 ? NB : E - H);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = p.S, hi = p.hi, T = p.T, N = p.N, cin = p.cin, ldq = p.ldq;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x;
-    const int st = tid / LPS, ph = tid % LPS;    // state and position inside its lane cluster
+    const int st = tid / LPS;
+    const int ph = LPS == 1 ? 0 : (tid & 1);      // half served by this lane
     const bool act = st < S;
-    const int stc = act ? st : S - 1;            // clamped state (always a valid column)
+    const int stc = act ? st : S - 1;              // clamped state (always a valid column)
+    const int kcnt = LPS == 1 ? E : (ph == 0 ? H : E - H);   // valid local edge indices: r < kcnt
 
-    constexpr int NR = (E + LPS * VW - 1) / (LPS * VW);   // BS*NR*VW >= LPS*S*NR*VW >= S*E >= cin
-    constexpr int NRQ = (E + 4 * LPS - 1) / (4 * LPS);   // 16-byte groups per thread of a Q row
-    constexpr int cpad = BS * 8;                          // staging row >= BS*NR*VW and >= BS*NRQ*4 (E <= 8)
-    const int lim_m = VW == 4 ? (cin + 3) & ~3 : cin;     // vector loads may touch the row's padding columns
+    constexpr int NRS = VW == 4 ? (E + 3) / 4 : E;     // staging pieces per thread (BS * NRS * VW >= S * E >= cin)
+    constexpr int cpad = BS * NRS * VW;                // staged row (floats)
+    const int lim_m = VW == 4 ? (cin + 3) & ~3 : cin;  // vector loads may touch the row's padding columns
     const int Tpad = (T + RDEPTH - 1) / RDEPTH * RDEPTH;
 
-    float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]  staged score / Q row
+    float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]  staged score row (sweep 2)
     float *sQ = sM + 2 * cpad;                                    // [2][cpad]  Q rows being assembled (sweep 2)
-    float *sA = sQ + 2 * cpad;                                    // [2][S]  alpha / beta
-    float *sX = sA + 2 * S;                                       // [2][S]  max-plus alpha / beta
+    float *sA = sQ + 2 * cpad;                                    // [2][S]  alpha (transposed order) / beta
+    float *sX = sA + 2 * S;                                       // [2][S]  max-plus alpha (transposed order) / beta
     float *sG = sX + 2 * S;                                       // [S]     scratch (logZ)
-    float *sRv = sG + S;                                          // [2][NW] arg-max partials
-    int *sRi = reinterpret_cast<int *>(sRv + 2 * NW);             // [2][NW]
-    float *sBc = reinterpret_cast<float *>(sRi + 2 * NW);         // [4] broadcast scratch
+    float *sRv = sG + S;                                          // [LRING][NW] arg-max partials: value
+    int *sRi = reinterpret_cast<int *>(sRv + LRING * NW);         // [LRING][NW] arg-max partials: flat edge index
+    float *sBc = reinterpret_cast<float *>(sRi + LRING * NW);     // [4] broadcast scratch
     int8_t *sLab = reinterpret_cast<int8_t *>(sBc + 4);           // [T]
 
     const float *sc = p.scores + (size_t)n * p.ld;
     const size_t tstride = (size_t)N * p.ld;
     float *alpha = p.alpha + (size_t)n * S;
-    float *beta = p.beta + (size_t)n * S;
     float *bmax = p.bmax + (size_t)n * S;
     const size_t sstride = (size_t)N * S;
     float *qrow = p.qbuf + (size_t)n * ldq;
     const size_t qstride = (size_t)N * ldq;
     const float blank = p.blank;
 
-    RowRegs<VW, NR, BS> ring[RDEPTH];
+    // logsumexp tail shared by sweeps 1 and 2: x[r] (invalid entries = -inf), mx = max over the state's edges.
+    // The exps are summed in edge order 0..E-1 (the contract's order; LPS == 2: pair_sum_ordered).
+    auto lse_tail = [&](const float (&x)[EPER], float mx) -> float {
+        float ex[EPER];
+#pragma unroll
+        for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(x[r] - mx);
+        float s;
+        if constexpr (LPS == 1) {
+            s = ex[0];
+#pragma unroll
+            for (int r = 1; r < EPER; ++r) s += ex[r];
+        } else {
+            s = pair_sum_ordered<E>(ex);
+        }
+        return mx + xb_logf(s);
+    };
+
+    // slot of state i in the transposed state vector of the destination-owned sweeps: the nb sources
+    // (k-1) * hi + j / nb, k = 1..nb, of a destination j are the contiguous slots (j / nb) * nb + (k - 1)
+    const int dj = stc, djq = dj / NB;
+    const int tpos = (dj % hi) * NB + dj / hi;
+    // LDS slot read for local edge r: r0slot for r == 0 (the stay edge = the state's own slot for the first half),
+    // sbase + r for r >= 1
+    const int sbase = djq * NB + (ph == 0 ? -1 : H - 1);
+    const int r0slot = ph == 0 ? tpos : djq * NB + H - 1;
 
     // ------------------------------------------------------------------ sweep 1: Log forward
-    if (tid < S) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }
-#pragma unroll
-    for (int d = 0; d < RDEPTH; ++d) ring[d].load(sc + (size_t)(d < T ? d : T - 1) * tstride, lim_m, tid);
-    for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
-#pragma unroll
-      for (int d = 0; d < RDEPTH; ++d) {
-        const int t = t0 + d;                                // >= T in the padding iterations
-        float *m = sM + (t & 1) * cpad;
-        ring[d].store(m, tid);
-        ring[d].load(sc + (size_t)(t + RDEPTH < T ? t + RDEPTH : T - 1) * tstride, lim_m, tid);
-        lds_barrier();
-        if (act && t < T) {
-            const float *a0 = sA + (t & 1) * S;
-            const int j = stc;
-            const int jq = j / NB;
-            float x[EPER];
-            float mx = -__builtin_inff();
-#pragma unroll
-            for (int r = 0; r < EPER; ++r) {
-                const int k = ph * EPER + r;                 // in-edge of state j (0 = stay)
-                const bool val = k < E;
-                const int kc = val ? k : 0;
-                const int src = kc == 0 ? j : (kc - 1) * hi + jq;
-                x[r] = val ? score_at<NB, HB>(m, j, kc, blank) + a0[src] : -__builtin_inff();
-                mx = maxf(mx, x[r]);
-            }
-            mx = cluster_max<LPS>(mx);
-            float ex[EPER];
-#pragma unroll
-            for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(x[r] - mx);
-            float s;
-            ordered_sum<LPS, E, EPER>(ex, s);
-            const float v = mx + xb_logf(s);
-            if (ph == 0) {
-                sA[((t + 1) & 1) * S + j] = v;
-                alpha[(size_t)(t + 1) * sstride + j] = v;
-            }
-        }
-      }
-    }
-    __syncthreads();
-
-    // logZ = logsumexp_j alpha_T[j], summed in order j = 0..S-1
     {
-        const float *aT = sA + (T & 1) * S;
-        if (tid == 0) {
-            float mx = aT[0];
-            for (int j = 1; j < S; ++j) mx = maxf(mx, aT[j]);
-            sBc[0] = mx;
+        const int j = dj;
+        // first score column this lane loads, and the register index of local edge r: mv[r + moff]
+        const int col0 = HB ? (ph == 0 ? j * E : j * E + E - EPER) : (ph == 0 ? j * NB : j * NB + H - 1);
+        if (tid < S) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }        // alpha_0 = 0 in any order
+        float ring[RDEPTH][CPL];
+#pragma unroll
+        for (int d = 0; d < RDEPTH; ++d) load_seg<CPL>(sc + (size_t)(d < T ? d : T - 1) * tstride + col0, ring[d]);
+        float aown = 0.0f;
+        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
+#pragma unroll
+          for (int d = 0; d < RDEPTH; ++d) {
+            const int t = t0 + d;                                // >= T in the padding iterations
+            float mv[CPL];
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) mv[r] = ring[d][r];
+            load_seg<CPL>(sc + (size_t)(t + RDEPTH < T ? t + RDEPTH : T - 1) * tstride + col0, ring[d]);
+            lds_barrier();
+            if (t < T) {                                         // block-uniform
+                const float *a0 = sA + (t & 1) * S;
+                float x[EPER];
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < EPER; ++r) {
+                    // score of local edge r.  Register index: with the blank column first half r, second half
+                    // r + (EPER - (E - H)); without it first half r - 1 (r >= 1; r == 0 is the constant blank), second
+                    // half r.  Indices are compile-time per half, the half is selected per lane.
+                    constexpr int SH = EPER - (E - H);           // 0 or 1
+                    float m0v, m1v;                              // value if this lane serves half 0 / half 1
+                    if (HB) {
+                        m0v = mv[r < CPL ? r : CPL - 1];
+                        m1v = mv[r + SH < CPL ? r + SH : CPL - 1];
+                    } else {
+                        m0v = r == 0 ? blank : mv[r - 1 < CPL ? r - 1 : CPL - 1];
+                        m1v = mv[r < CPL ? r : CPL - 1];
+                    }
+                    const float mk = (LPS == 1 || ph == 0) ? m0v : m1v;
+                    float ak;
+                    if (r == 0) ak = LPS == 1 ? aown : a0[r0slot];
+                    else ak = a0[sbase + r];
+                    x[r] = r < kcnt ? mk + ak : -__builtin_inff();
+                    mx = maxf(mx, x[r]);
+                }
+                if (LPS == 2) mx = pair_max(mx);
+                const float v = lse_tail(x, mx);
+                aown = v;
+                if (ph == 0 && act) {
+                    sA[((t + 1) & 1) * S + tpos] = v;
+                    alpha[(size_t)(t + 1) * sstride + j] = v;
+                }
+            }
+          }
         }
         __syncthreads();
-        const float mx = sBc[0];
-        if (tid < S) sG[tid] = xb_expf(aT[tid] - mx);
+    }
+
+    // logZ = logsumexp_j alpha_T[j], summed in order j = 0..S-1 (alpha_T sits in LDS in transposed order)
+    {
+        const float *aT = sA + (T & 1) * S;
+        const int tp = tid < S ? (tid % hi) * NB + tid / hi : 0;
+        const float mine = aT[tp];
+        const float wm = wave_max63(tid < S ? mine : -__builtin_inff());
+        if (lane == 63) sRv[wave] = wm;                          // the partial ring is free until sweep 3
+        __syncthreads();
+        float mx = sRv[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mx = maxf(mx, sRv[w]);
+        if (tid < S) sG[tid] = xb_expf(mine - mx);
         __syncthreads();
         if (tid == 0) {
             float s = sG[0];
@@ -311,16 +397,28 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 
     // -------------------------------------------- sweep 2: Log backward + Max backward (fused)
     {
+        // source state of this lane (pair), permuted: consecutive groups of NB sources share their NB destinations
+        // (i = (st % NB) * hi + st / NB), so the strided reads of the staged row are contiguous inside a group
+        const int i = (stc % NB) * hi + stc / NB;
+        const int kk = stc % NB + 1;                               // = i / hi + 1: column of the new-base edges
+        const int jb = (stc / NB) * NB;                            // = (i % hi) * NB: first destination
         if (tid < S) {
             sA[(T & 1) * S + tid] = 0.0f;
             sX[(T & 1) * S + tid] = 0.0f;
-            beta[(size_t)T * sstride + tid] = 0.0f;
             bmax[(size_t)T * sstride + tid] = 0.0f;
         }
-        // cluster = source state i; lane ph owns the out-edges e = ph*EPER .. (0 = stay, e >= 1 = new base e-1)
-        const int i = stc;
-        const int kk = i / hi + 1;
-        const int jb = (i % hi) * NB;
+        // per-lane constants of local edge r: destination state and staged-row index of its score
+        // (e = 0: stay, j = i, column 0; e >= 1: j = jb + e - 1, column kk)
+        int dstj[EPER], midx[EPER];
+#pragma unroll
+        for (int r = 0; r < EPER; ++r) {
+            const int e = (LPS == 1 ? 0 : ph * H) + r;
+            const bool val = r < kcnt;
+            const int j = e == 0 ? i : (val ? jb + e - 1 : jb);
+            dstj[r] = j;
+            midx[r] = HB ? j * E + (e == 0 ? 0 : kk) : (e == 0 ? 0 : j * NB + kk - 1);
+        }
+        const bool stay0 = LPS == 1 || ph == 0;                    // local edge 0 is the stay edge
         // the Q row of step t is complete once every thread has passed the barrier of step t-1:
         // it is stored (coalesced 16-byte groups) during iteration t-1
         auto store_qrow = [&](int t) {
@@ -329,6 +427,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             for (int g = tid * 4; g < ldq; g += BS * 4)
                 *reinterpret_cast<f32x4 *>(dst + g) = *reinterpret_cast<const f32x4 *>(src + g);
         };
+        typename std::conditional<VW == 4, RowRegs<NRS, BS>, RowRegs1<NRS, BS>>::type ring[RDEPTH];
         float aring[RDEPTH];
 #pragma unroll
         for (int d = 0; d < RDEPTH; ++d) {
@@ -339,7 +438,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         for (int s0 = 0; s0 < Tpad; s0 += RDEPTH) {
 #pragma unroll
           for (int d = 0; d < RDEPTH; ++d) {
-            const int t = T - 1 - (s0 + d);                  // < 0 in the padding iterations
+            const int t = T - 1 - (s0 + d);                      // < 0 in the padding iterations
             float *m = sM + (t & 1) * cpad;
             ring[d].store(m, tid);
             const float a0 = aring[d];
@@ -350,7 +449,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             }
             lds_barrier();
             if (t >= 0 && t + 1 < T) store_qrow(t + 1);
-            if (act && t >= 0) {
+            if (t >= 0) {                                        // block-uniform
                 float *qs = sQ + (t & 1) * cpad;
                 const float *b1 = sA + ((t + 1) & 1) * S;
                 const float *m1 = sX + ((t + 1) & 1) * S;
@@ -358,34 +457,26 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 float mx = -__builtin_inff(), mm = -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < EPER; ++r) {
-                    const int e = ph * EPER + r;
-                    const bool val = e < E;
-                    const int ee = val ? e : 0;
-                    const int j = ee == 0 ? i : jb + ee - 1;
-                    const int k = ee == 0 ? 0 : kk;
-                    const float mv = score_at<NB, HB>(m, j, k, blank);
-                    const float bj = b1[j];
+                    const bool val = r < kcnt;
+                    float mv = m[midx[r]];
+                    if (!HB && r == 0) mv = stay0 ? blank : mv;
+                    const float bj = b1[dstj[r]];
+                    const float mj = m1[dstj[r]];
                     const float xx = ((a0 + mv) + bj) - logZ;
                     const float q = xb_logf(xb_expf(xx) + 1e-8f);
                     y[r] = val ? mv + bj : -__builtin_inff();
                     if (val) {
-                        qs[j * E + k] = q;
+                        const int k = (r == 0 && stay0) ? 0 : kk;
+                        if (act) qs[dstj[r] * E + k] = q;
                         mx = maxf(mx, y[r]);
-                        mm = maxf(mm, q + m1[j]);
+                        mm = maxf(mm, q + mj);
                     }
                 }
-                mx = cluster_max<LPS>(mx);
-                mm = cluster_max<LPS>(mm);
-                float ex[EPER];
-#pragma unroll
-                for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(y[r] - mx);
-                float sm;
-                ordered_sum<LPS, E, EPER>(ex, sm);
-                const float bv = mx + xb_logf(sm);
-                if (ph == 0) {
+                if (LPS == 2) { mx = pair_max(mx); mm = pair_max(mm); }
+                const float bv = lse_tail(y, mx);
+                if (ph == 0 && act) {
                     sA[(t & 1) * S + i] = bv;
                     sX[(t & 1) * S + i] = mm;
-                    beta[(size_t)t * sstride + i] = bv;
                     bmax[(size_t)t * sstride + i] = mm;
                 }
             }
@@ -401,79 +492,95 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 #endif
     // --------------------------- sweep 3: Max forward over Q + per-step arg-max of the max-marginals
     {
+        const int j = dj;
+        constexpr int SH = EPER - (E - H);                        // register shift of the second half (0 or 1)
+        const int col0 = ph == 0 ? j * E : j * E + E - EPER;      // this lane's first Q column (never past the row)
+        const int k0 = LPS == 1 ? 0 : ph * H;
         if (tid < S) sX[tid] = 0.0f;
-        RowRegs<4, NRQ, BS> qring[RDEPTH];
+        float qring[RDEPTH][EPER];
         float mring[RDEPTH];
 #pragma unroll
         for (int d = 0; d < RDEPTH; ++d) {
             const int t = d < T ? d : T - 1;
-            qring[d].load(qrow + (size_t)t * qstride, ldq, tid);
-            mring[d] = bmax[(size_t)(t + 1) * sstride + stc];
+            load_seg<EPER>(qrow + (size_t)t * qstride + col0, qring[d]);
+            mring[d] = bmax[(size_t)(t + 1) * sstride + j];
         }
-        const int j = stc;
-        const int jq = j / NB;
-        const int wave = tid >> 6;
+        // finalise the labels of steps [tb, tb + 64): lane l of the calling wave takes step tb + l
+        auto finalise = [&](int tb) {
+            const int t = tb + lane;
+            if (t < T) {
+                const float *rv = sRv + (t & (LRING - 1)) * NW;
+                const int *ri = sRi + (t & (LRING - 1)) * NW;
+                float bv = rv[0];
+                int bi = ri[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const float v = rv[w];
+                    const int c = ri[w];
+                    if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+                }
+                sLab[t] = (int8_t)(bi % E);
+            }
+        };
+        float aown = 0.0f;
         for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
 #pragma unroll
           for (int d = 0; d < RDEPTH; ++d) {
-            const int t = t0 + d;                            // >= T in the padding iterations
-            float *m = sM + (t & 1) * cpad;
-            qring[d].store(m, tid);
+            const int t = t0 + d;                                // >= T in the padding iterations
+            float qv[EPER];
+#pragma unroll
+            for (int r = 0; r < EPER; ++r) qv[r] = qring[d][r];
             const float m1j = mring[d];
             {
                 const int tn = t + RDEPTH < T ? t + RDEPTH : T - 1;
-                qring[d].load(qrow + (size_t)tn * qstride, ldq, tid);
-                mring[d] = bmax[(size_t)(tn + 1) * sstride + stc];
+                load_seg<EPER>(qrow + (size_t)tn * qstride + col0, qring[d]);
+                mring[d] = bmax[(size_t)(tn + 1) * sstride + j];
             }
             lds_barrier();
-            // finalise the previous step's arg-max (partials were written before this barrier)
-            if (tid == 0 && t > 0 && t <= T) {
-                const float *rv = sRv + ((t - 1) & 1) * NW;
-                const int *ri = sRi + ((t - 1) & 1) * NW;
-                float bv = rv[0];
-                int bi = ri[0];
-                for (int w = 1; w < NW; ++w)
-                    if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-                sLab[t - 1] = (int8_t)(bi % E);
-            }
-            if (t < T) {                                     // wave-uniform
-            float best = -__builtin_inff();
-            int bestc = 0x7fffffff;
-            if (act) {
+            // every 64 steps one wave (taking turns) finalises the 64 steps before this one: their partials were all
+            // written before this barrier, and the ring slots being rewritten meanwhile are 64 steps away
+            if ((t & 63) == 0 && t > 0 && t <= T && wave == ((t >> 6) % NW)) finalise(t - 64);
+            if (t < T) {                                         // block-uniform
                 const float *am = sX + (t & 1) * S;
                 float mm = -__builtin_inff();
+                float best = -__builtin_inff();
+                int bestc = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < EPER; ++r) {
-                    const int k = ph * EPER + r;             // in-edge of state j, increasing flat index
-                    if (k < E) {
-                        const int src = k == 0 ? j : (k - 1) * hi + jq;
-                        const float Q = m[j * E + k];
-                        const float av = am[src];
+                    const float Q = (LPS == 1 || ph == 0) ? qv[r] : qv[r + SH < EPER ? r + SH : EPER - 1];
+                    float av;
+                    if (r == 0) av = LPS == 1 ? aown : am[r0slot];
+                    else av = am[sbase + r];
+                    if (r < kcnt) {
                         mm = maxf(mm, Q + av);
                         const float scv = (av + Q) + m1j;
-                        if (scv > best) { best = scv; bestc = j * E + k; }
+                        if (scv > best) { best = scv; bestc = j * E + k0 + r; }   // increasing flat index
                     }
                 }
-                mm = cluster_max<LPS>(mm);
-                if (ph == 0) sX[((t + 1) & 1) * S + j] = mm;
-            }
-            wave_argmax(best, bestc);
-            if (lane == 63) {
-                sRv[(t & 1) * NW + wave] = best;
-                sRi[(t & 1) * NW + wave] = bestc;
-            }
+                if (LPS == 2) mm = pair_max(mm);
+                aown = mm;
+                if (ph == 0 && act) sX[((t + 1) & 1) * S + tpos] = mm;
+                // arg-max over the workgroup's edges: lanes are in flat-index order (state major, the two halves of a
+                // state on adjacent lanes), each lane holds its lowest-index maximiser, so the lowest lane that attains
+                // the wave maximum holds the wave's lowest flat index
+                if (!act) best = -__builtin_inff();
+                const float wmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max63(best)), 63));
+                const unsigned long long hit = __ballot(best == wmx);
+                const int wl = __builtin_amdgcn_readfirstlane(hit ? (int)__builtin_ctzll(hit) : 0);
+                const int wc = __builtin_amdgcn_readlane(bestc, wl);
+                if (lane == 0) {
+                    sRv[(t & (LRING - 1)) * NW + wave] = wmx;
+                    sRi[(t & (LRING - 1)) * NW + wave] = wc;
+                }
             }
           }
         }
         __syncthreads();
-        if (tid == 0 && Tpad == T) {                             // otherwise a padding iteration already did it
-            const float *rv = sRv + ((T - 1) & 1) * NW;
-            const int *ri = sRi + ((T - 1) & 1) * NW;
-            float bv = rv[0];
-            int bi = ri[0];
-            for (int w = 1; w < NW; ++w)
-                if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-            sLab[T - 1] = (int8_t)(bi % E);
+        // the loop finalised steps [0, done): its iterations t = 64, 128, .. <= min(T, Tpad - 1)
+        {
+            const int last = T < Tpad - 1 ? T : Tpad - 1;
+            const int done = (last / 64) * 64;
+            if (wave == 0) for (int tb = done; tb < T; tb += 64) finalise(tb);
         }
         __syncthreads();
     }
@@ -482,7 +589,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     if (p.labels)
         for (int t = tid; t < T; t += BS) p.labels[(size_t)n * T + t] = sLab[t];
     if (p.seq || p.seq_len) {
-        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints; the row ring is free now (size checked on host)
+        int *sCnt = reinterpret_cast<int *>(sM);      // BS+1 ints; the row staging is free now
         const int per = (T + BS - 1) / BS;
         const int lo = tid * per, hiT = (lo + per < T) ? lo + per : T;
         int cnt = 0;
@@ -512,28 +619,30 @@ template <int NB, int BS, int LPS>
 hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
     // must mirror the kernel's LDS carve
-    const int cpad = BS * 8;
-    size_t lds = sizeof(float) * (4 * (size_t)cpad + 5 * (size_t)p.S + 2 * (BS / 64)) + sizeof(int) * 2 * (BS / 64) +
-                 sizeof(float) * 4 + (size_t)p.T;
+    constexpr int E = NB + 1;
+    const int nrs = vw == 4 ? (E + 3) / 4 : E;
+    const size_t cpad = (size_t)BS * nrs * vw;
+    size_t lds = sizeof(float) * (4 * cpad + 5 * (size_t)p.S + (size_t)LRING * (BS / 64)) +
+                 sizeof(int) * (size_t)LRING * (BS / 64) + sizeof(float) * 4 + (size_t)p.T;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(p.N), block(BS);
-#define XB_LAUNCH(VW, HB)                                                                                          \
+#define XB_LAUNCH(HB, VW)                                                                                          \
     do {                                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_decode_kernel<NB, BS, VW, HB, LPS>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_decode_kernel<NB, BS, HB, LPS, VW>),         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        hipLaunchKernelGGL((crf_decode_kernel<NB, BS, VW, HB, LPS>), grid, block, lds, stream, p);                 \
+        hipLaunchKernelGGL((crf_decode_kernel<NB, BS, HB, LPS, VW>), grid, block, lds, stream, p);                 \
     } while (0)
     if (p.has_blank) {
-        if (vw == 4) XB_LAUNCH(4, true); else XB_LAUNCH(1, true);
+        if (vw == 4) XB_LAUNCH(true, 4); else XB_LAUNCH(true, 1);
     } else {
-        if (vw == 4) XB_LAUNCH(4, false); else XB_LAUNCH(1, false);
+        if (vw == 4) XB_LAUNCH(false, 4); else XB_LAUNCH(false, 1);
     }
 #undef XB_LAUNCH
     return hipGetLastError();
 }
 
-// Block = smallest of 64/128/256/512/1024 threads that holds LPS lanes for each of the S states.
+// Block = smallest multiple of 64 threads (from a short list, pruned per alphabet) that holds LPS lanes for each state.
 template <int NB, int LPS>
 hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
@@ -541,18 +650,21 @@ hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
     if (need <= 64) return launch_nb_bs<NB, 64, LPS>(p, vw, stream);
     if (need <= 128) return launch_nb_bs<NB, 128, LPS>(p, vw, stream);
     if (need <= 256) return launch_nb_bs<NB, 256, LPS>(p, vw, stream);
-    if (need <= 512) return launch_nb_bs<NB, 512, LPS>(p, vw, stream);
-    if (LPS == 1 && need <= 1024) return launch_nb_bs<NB, 1024, 1>(p, vw, stream);
+    if constexpr (NB == 6) {
+        if (need <= 448) return launch_nb_bs<NB, 448, LPS>(p, vw, stream);     // 2 x 216 states
+    } else {
+        if (need <= 640) return launch_nb_bs<NB, 640, LPS>(p, vw, stream);     // 5^4 states / 2 x 4^4
+        if constexpr (NB == 4 && LPS == 1) {
+            if (need <= 1024) return launch_nb_bs<NB, 1024, LPS>(p, vw, stream);   // 4^5 states
+        }
+    }
     return hipErrorInvalidValue;
 }
 template <int NB>
 hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    switch (xb::decode_lanes_per_state(p.S, p.N)) {
-    case 4: return launch_nb_lps<NB, 4>(p, vw, stream);
-    case 2: return launch_nb_lps<NB, 2>(p, vw, stream);
-    default: return launch_nb_lps<NB, 1>(p, vw, stream);
-    }
+    if (xb::decode_lanes_per_state(p.S, p.N) == 2) return launch_nb_lps<NB, 2>(p, vw, stream);
+    return launch_nb_lps<NB, 1>(p, vw, stream);
 }
 
 }  // namespace
@@ -563,23 +675,22 @@ int decode_lanes_per_state(int S, int N)
 {
     if (const char *e = getenv("XB_DECODE_LPS")) {
         const int v = atoi(e);
-        if ((v == 1 || v == 2 || v == 4) && v * S <= 512) return v;
+        if ((v == 1 || v == 2) && v * S <= 1024) return v;
     }
-    // measured on MI355X (T = 2000).  The kernel is VALU-issue bound, lane clusters duplicate the per-state work: two lanes
-    // per state win while the block stays <= 256 threads and the batch leaves the CUs few workgroups each (N = 512, S = 64:
-    // 4.7 vs 4.9 ms, S = 125: 5.4 vs 6.7 ms; S = 216 in a 512-thread block loses, 9.7 vs 8.5 ms); with many chunks per CU one
-    // lane per state is ahead for the small state space (N = 2048, S = 64: 6.9 vs 8.1 ms) but not for S = 125 (16.9 vs 16.0)
-    if (2 * S > 256) return 1;
-    if (S <= 64 && N >= 1024) return 1;
-    return 2;
+    (void)N;
+    // two lanes per state halve the per-lane chain of exps (a step is bound by its dependency chain) at the price of a
+    // workgroup twice as wide; measured on MI355X, N = 512, T = 2000: S = 125: 3.84 (2 lanes) vs 4.87 ms (1 lane);
+    // S = 216: 8.57 (448 threads) vs 6.54 ms (256 threads)
+    return 2 * S <= 256 ? 2 : 1;
 }
 
 // Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:
 //   S = NB^state_len <= 1024, cin = S*(NB+1) or S*NB, ld >= cin (the pack scratch of BS+1 ints always
-//   fits the 2*BS*NR*VW-float staging area).
+//   fits the staging area).
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
 {
     if (p.S < 1 || p.S > 1024 || p.T < 1 || p.N < 1) return hipErrorInvalidValue;
+    if (p.S % p.nb != 0 || p.hi * p.nb != p.S) return hipErrorInvalidValue;
     const int E = p.nb + 1;
     if (p.cin != (p.has_blank ? p.S * E : p.S * p.nb) || p.ld < p.cin) return hipErrorInvalidValue;
     if (!p.qbuf || p.ldq % 4 != 0 || p.ldq < p.S * E || reinterpret_cast<uintptr_t>(p.qbuf) % 16 != 0) return hipErrorInvalidValue;
