@@ -130,6 +130,16 @@ XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, con
 
 XB_API int xb_synchronize(xb_ctx *ctx);
 
+/*
+ * The HIP stream (a hipStream_t, returned as void *) on which the outputs of the most recent *_dev call are produced.
+ * A caller that consumes d_seq / d_seq_len on a stream of its own without a host-side xb_synchronize records an event
+ * on this stream right after the call and waits for it there; before the same output buffers are handed to a later
+ * call it makes this stream wait for its own "consumed" event.  This is how the gather of called sequences
+ * (RCCL all_gather on a side stream) overlaps the next batch; the reference, single-device Python, has no
+ * counterpart.
+ */
+XB_API void *xb_result_stream(xb_ctx *ctx);
+
 /* ---- introspection / measurement ---------------------------------------------------------- */
 
 enum { XB_STAGE_CONV = 0, XB_STAGE_LSTM_IN = 1, XB_STAGE_LSTM_REC = 2, XB_STAGE_LINEAR = 3,

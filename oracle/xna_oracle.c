@@ -63,12 +63,16 @@
 static inline float xo_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t xo_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* exp(x) with the argument clamped to [-87, 88] (no flush to zero: exp(-87) = 1.6e-38 stands for anything smaller). */
+/* exp(x) with the argument clamped to [-87, 88] (no flush to zero: exp(-87) = 1.6e-38 stands for anything smaller).
+ * n = round-to-nearest-even of x*log2(e) comes from ONE fma against the magic constant 1.5*2^23 (the integer then sits in
+ * the low mantissa bits of t, which also gives 2^n by a shift): no rint / float->int conversion, every step has a packed
+ * (two values per instruction) form on the GPU. */
 static inline float xo_expf_i(float x)
 {
     x = x < -87.0f ? -87.0f : x;
     x = x > 88.0f ? 88.0f : x;
-    float n = rintf(x * 1.44269504088896341f);
+    const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
@@ -79,8 +83,7 @@ static inline float xo_expf_i(float x)
     p = fmaf(p, r, 5.0000001201e-1f);
     float r2 = r * r;
     float y = fmaf(p, r2, r) + 1.0f;
-    int32_t ni = (int32_t)n;
-    float s = xo_bits2f((uint32_t)(ni + 127) << 23);
+    float s = xo_bits2f((xo_f2bits(t) << 23) + 0x3f800000u);      /* 2^n, n in [-126, 127] */
     return y * s;
 }
 

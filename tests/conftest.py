@@ -33,39 +33,7 @@ def make_config(features=768, labels=("N", "A", "C", "G", "T", "X", "Y")):
     return c
 
 
-def seeded_state_dict(keys, shapes, seed):
-    """Same generator as tests/golden/make_golden.py:seeded_state_dict (weights are not stored for the
-    full-size fixture, they are regenerated)."""
-    rng = np.random.default_rng(seed)
-    out = {}
-    for k, shp in zip(keys, shapes):
-        shp = tuple(shp)
-        if k.endswith("bias_hh_l0"):
-            a = np.zeros(shp, np.float32)
-        elif "bias" in k:
-            a = np.clip(0.5 * rng.standard_normal(shp), -1, 1).astype(np.float32)
-        else:
-            fan_in = int(np.prod(shp[1:]))
-            a = (rng.standard_normal(shp) / np.sqrt(fan_in)).astype(np.float32)
-        out[k] = a
-    return out
-
-
-def encoder_shapes(features, n_base, state_len=3, winlen=19):
-    import oracle
-    F = features
-    shapes = {"encoder.0.conv.weight": (4, 1, 5), "encoder.0.conv.bias": (4,),
-              "encoder.1.conv.weight": (16, 4, 5), "encoder.1.conv.bias": (16,),
-              "encoder.2.conv.weight": (F, 16, winlen), "encoder.2.conv.bias": (F,),
-              "encoder.9.linear.weight": (n_base ** (state_len + 1), F),
-              "encoder.9.linear.bias": (n_base ** (state_len + 1),)}
-    for l in range(4, 9):
-        shapes["encoder.%d.rnn.weight_ih_l0" % l] = (4 * F, F)
-        shapes["encoder.%d.rnn.weight_hh_l0" % l] = (4 * F, F)
-        shapes["encoder.%d.rnn.bias_ih_l0" % l] = (4 * F,)
-        shapes["encoder.%d.rnn.bias_hh_l0" % l] = (4 * F,)
-    keys = list(oracle.STATE_DICT_ORDER)
-    return keys, [shapes[k] for k in keys]
+from xna_basecaller_amd.synthetic import encoder_shapes, seeded_state_dict  # noqa: E402,F401  (re-exported for the tests)
 
 
 def random_scores(T, N, nb, sl=3, seed=0, blank=2.0, with_blank=True):

@@ -37,6 +37,23 @@ lens = torch.tensor([rank, 2, 3], dtype=torch.int32)
 s, l = xd.gather_packed(seq, lens)
 assert s.shape == (2, 3, 8) and l.shape == (2, 3)
 assert s[0, 0, 0].item() == 65 and s[1, 2, 7].item() == 66 and l[:, 0].tolist() == [0, 1]
+# deferred (one batch late) gather used by bench.py and the CLI: results come back in submission order, one call late
+dg = xd.DeferredGather()
+outs = []
+for k in range(5):
+    seq = torch.full((2, 4), 10 * k + rank, dtype=torch.int8)
+    lens = torch.tensor([k, rank], dtype=torch.int32)
+    r = dg.submit(seq, lens)
+    assert (r is None) == (k == 0)
+    if r is not None:
+        outs.append(r)
+outs.append(dg.flush())
+assert dg.flush() is None
+assert len(outs) == 5
+for k, (s, l) in enumerate(outs):
+    assert s.shape == (2, 2, 4) and l.shape == (2, 2)
+    assert s[0, 0, 0].item() == 10 * k and s[1, 1, 3].item() == 10 * k + 1
+    assert l[0].tolist() == [k, 0] and l[1].tolist() == [k, 1]
 xd.barrier()
 print("rank", rank, "ok")
 '''

@@ -20,7 +20,7 @@ EXPORTS = [
     "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",
     "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev",
     "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
-    "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version",
+    "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
 ]
 
 
@@ -70,6 +70,8 @@ def load():
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
+    lib.xb_result_stream.argtypes = [vp]
+    lib.xb_result_stream.restype = C.c_void_p
     lib.xb_set_profiling.argtypes = [vp, ip]
     lib.xb_get_stage_times.argtypes = [vp, vp, vp]
     lib.xb_reset_stage_times.argtypes = [vp]
@@ -182,6 +184,10 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.xb_synchronize(self.h))
+
+    def result_stream(self):
+        """hipStream_t (int) producing the outputs of the most recent *_dev call (xb_result_stream)."""
+        return int(self.lib.xb_result_stream(self.h) or 0)
 
     def set_profiling(self, on):
         self._check(self.lib.xb_set_profiling(self.h, int(bool(on))))

@@ -42,6 +42,7 @@ struct xb_ctx {
     hipEvent_t dec_done[2] = {};     // decode that last read scores buffer p has finished
     bool dec_pending[2] = {};
     unsigned batch_idx = 0;
+    hipStream_t result_stream = nullptr;   // stream that produces the outputs of the most recent *_dev call
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
     size_t dep_next = 0;
     int overlap = 1, time_slabs = 16;   // XB_OVERLAP / XB_TIME_SLABS (upper bound; a slab is at least 125 steps)
@@ -684,12 +685,19 @@ XB_API int xb_synchronize(xb_ctx *ctx)
     return check_device_error(ctx);
 }
 
+XB_API void *xb_result_stream(xb_ctx *ctx)
+{
+    if (!ctx) return nullptr;
+    return ctx->result_stream ? ctx->result_stream : ctx->stream;
+}
+
 XB_API int xb_encode_dev(xb_ctx *ctx, const float *d_signal, int n, int expand_blanks, float *d_scores)
 {
     int rc = check_ready(ctx, n);
     if (rc) return rc;
     if (!d_signal || !d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->result_stream = ctx->stream;
     if ((rc = join_async_decode(ctx))) return rc;
     const int ldc = expand_blanks ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     return run_encoder(ctx, d_signal, n, expand_blanks ? 1 : 0, d_scores, ldc);
@@ -720,6 +728,7 @@ XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int h
     if (!d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
     XB_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = join_async_decode(ctx)) return rc;
+    ctx->result_stream = ctx->stream;
     const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, alphabet, d_labels, d_seq, d_seq_len);
 }
@@ -752,6 +761,7 @@ XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, con
     if (!d_signal || !d_seq || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
     XB_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->overlap || !ctx->stream3 || !ctx->scores2) {
+        ctx->result_stream = ctx->stream;
         rc = run_encoder(ctx, d_signal, n, 0, ctx->scores, ctx->ld_nb);
         if (rc) return rc;
         return run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len);
@@ -760,6 +770,7 @@ XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, con
     // still be reading buffer p ^ 1 on the third stream; the decode that used buffer p two calls ago must be done first
     const int pb = (int)(ctx->batch_idx++ & 1u);
     float *sc = pb ? ctx->scores2 : ctx->scores;
+    ctx->result_stream = ctx->stream3;
     if (ctx->dec_pending[pb]) XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[pb], 0));
     rc = run_encoder(ctx, d_signal, n, 0, sc, ctx->ld_nb);
     if (rc) return rc;

@@ -47,10 +47,23 @@ namespace {
 __device__ __forceinline__ float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// ---- the contract's exp / log, scalar and two-wide.  The two-wide forms run the SAME IEEE operations on both
+// elements with v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (a plain wave64 VALU instruction and a packed one both occupy
+// the SIMD for 4 cycles, and the kernel is bound by VALU issue); only the integer steps stay per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+constexpr float XB_EXP_MAGIC = 12582912.0f;     // 1.5 * 2^23: fma(x, log2e, magic) leaves round(x log2e) in the low mantissa bits
+__device__ __forceinline__ float xb_exp_scale(float t)   // 2^n from t = magic + n
+{
+    return bits2f((f2bits(t) << 23) + 0x3f800000u);
+}
 __device__ __forceinline__ float xb_expf(float x)
 {
     x = __builtin_amdgcn_fmed3f(x, -87.0f, 88.0f);              // clamp (one instruction), no flush to zero
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    const float t = __builtin_fmaf(x, 1.44269504088896341f, XB_EXP_MAGIC);
+    const float n = t - XB_EXP_MAGIC;
     float r = __builtin_fmaf(n, -0.693359375f, x);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
@@ -61,12 +74,30 @@ __device__ __forceinline__ float xb_expf(float x)
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     const float r2 = r * r;
     const float y = __builtin_fmaf(p, r2, r) + 1.0f;
-    const int ni = (int)n;
-    const float s = bits2f((uint32_t)(ni + 127) << 23);
-    return y * s;
+    return y * xb_exp_scale(t);
+}
+__device__ __forceinline__ f32x2 xb_expf2(f32x2 x)
+{
+    x.x = __builtin_amdgcn_fmed3f(x.x, -87.0f, 88.0f);
+    x.y = __builtin_amdgcn_fmed3f(x.y, -87.0f, 88.0f);
+    const f32x2 t = fma2(x, splat2(1.44269504088896341f), splat2(XB_EXP_MAGIC));
+    const f32x2 n = t - splat2(XB_EXP_MAGIC);
+    f32x2 r = fma2(n, splat2(-0.693359375f), x);
+    r = fma2(n, splat2(2.12194440e-4f), r);
+    f32x2 p = splat2(1.9875691500e-4f);
+    p = fma2(p, r, splat2(1.3981999507e-3f));
+    p = fma2(p, r, splat2(8.3334519073e-3f));
+    p = fma2(p, r, splat2(4.1665795894e-2f));
+    p = fma2(p, r, splat2(1.6666665459e-1f));
+    p = fma2(p, r, splat2(5.0000001201e-1f));
+    const f32x2 r2 = r * r;
+    const f32x2 y = fma2(p, r2, r) + splat2(1.0f);
+    const f32x2 sc = {xb_exp_scale(t.x), xb_exp_scale(t.y)};
+    return y * sc;
 }
 
-__device__ __forceinline__ float xb_logf(float x)
+// range reduction of the log: x = m * 2^e with m in (sqrt(1/2), sqrt(2)]; returns f = m - 1 and e as a float
+__device__ __forceinline__ void xb_log_reduce(float x, float &f, float &fe)
 {
     const uint32_t ix = f2bits(x);
     int e = (int)(ix >> 23) - 127;
@@ -74,7 +105,13 @@ __device__ __forceinline__ float xb_logf(float x)
     const bool big = m > 1.41421356237309505f;
     m = big ? m * 0.5f : m;
     e = big ? e + 1 : e;
-    const float f = m - 1.0f;
+    f = m - 1.0f;
+    fe = (float)e;
+}
+__device__ __forceinline__ float xb_logf(float x)
+{
+    float f, fe;
+    xb_log_reduce(x, f, fe);
     const float z = f * f;
     const float z2 = z * z;
     const float z4 = z2 * z2;
@@ -87,12 +124,65 @@ __device__ __forceinline__ float xb_logf(float x)
     const float q07 = __builtin_fmaf(q47, z2, q03);
     const float p = __builtin_fmaf(7.0376836292e-2f, z4, q07);
     float y = (f * z) * p;
-    const float fe = (float)e;
     y = __builtin_fmaf(fe, -2.12194440e-4f, y);
     y = __builtin_fmaf(-0.5f, z, y);
     float r = f + y;
     r = __builtin_fmaf(fe, 0.693359375f, r);
     return r;
+}
+__device__ __forceinline__ f32x2 xb_logf2(f32x2 x)
+{
+    f32x2 f, fe;
+    {
+        float f0, f1, e0, e1;
+        xb_log_reduce(x.x, f0, e0);
+        xb_log_reduce(x.y, f1, e1);
+        f = (f32x2){f0, f1};
+        fe = (f32x2){e0, e1};
+    }
+    const f32x2 z = f * f;
+    const f32x2 z2 = z * z;
+    const f32x2 z4 = z2 * z2;
+    const f32x2 q01 = fma2(splat2(-2.4999993993e-1f), f, splat2(3.3333331174e-1f));
+    const f32x2 q23 = fma2(splat2(-1.6668057665e-1f), f, splat2(2.0000714765e-1f));
+    const f32x2 q45 = fma2(splat2(-1.2420140846e-1f), f, splat2(1.4249322787e-1f));
+    const f32x2 q67 = fma2(splat2(-1.1514610310e-1f), f, splat2(1.1676998740e-1f));
+    const f32x2 q03 = fma2(q23, z, q01);
+    const f32x2 q47 = fma2(q67, z, q45);
+    const f32x2 q07 = fma2(q47, z2, q03);
+    const f32x2 p = fma2(splat2(7.0376836292e-2f), z4, q07);
+    f32x2 y = (f * z) * p;
+    y = fma2(fe, splat2(-2.12194440e-4f), y);
+    y = fma2(splat2(-0.5f), z, y);
+    f32x2 r = f + y;
+    r = fma2(fe, splat2(0.693359375f), r);
+    return r;
+}
+
+// log of N values, two at a time (the odd last one alone)
+template <int N>
+__device__ __forceinline__ void xb_log_n(const float (&x)[N], float (&y)[N])
+{
+#pragma unroll
+    for (int r = 0; r + 1 < N; r += 2) {
+        const f32x2 v = xb_logf2((f32x2){x[r], x[r + 1]});
+        y[r] = v.x;
+        y[r + 1] = v.y;
+    }
+    if (N & 1) y[N - 1] = xb_logf(x[N - 1]);
+}
+
+// exp of N values, two at a time (the odd last one alone)
+template <int N>
+__device__ __forceinline__ void xb_exp_n(const float (&x)[N], float (&y)[N])
+{
+#pragma unroll
+    for (int r = 0; r + 1 < N; r += 2) {
+        const f32x2 v = xb_expf2((f32x2){x[r], x[r + 1]});
+        y[r] = v.x;
+        y[r + 1] = v.y;
+    }
+    if (N & 1) y[N - 1] = xb_expf(x[N - 1]);
 }
 
 __device__ __forceinline__ float maxf(float a, float b) { return b > a ? b : a; }
@@ -127,6 +217,24 @@ __device__ __forceinline__ float wave_max63(float v)
         "s_nop 1"
         : "+v"(v));
     return v;
+}
+// the same for four independent values at once: the four chains interleave, which also provides the two wait states
+// between a register's write and its next DPP read (no s_nop between the levels)
+__device__ __forceinline__ void wave_max63_x4(float &a, float &b, float &c, float &d)
+{
+#define XB_L4(ctrl) \
+    "v_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\t" \
+    "v_max_f32_dpp %2, %2, %2 " ctrl "\n\tv_max_f32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 XB_L4("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 XB_L4("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 XB_L4("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 XB_L4("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 XB_L4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 XB_L4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef XB_L4
 }
 // max / sum with the partner lane of a pair (lanes 2s, 2s+1): both lanes receive the result
 __device__ __forceinline__ float pair_max(float v)
@@ -288,9 +396,10 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     // logsumexp tail shared by sweeps 1 and 2: x[r] (invalid entries = -inf), mx = max over the state's edges.
     // The exps are summed in edge order 0..E-1 (the contract's order; LPS == 2: pair_sum_ordered).
     auto lse_tail = [&](const float (&x)[EPER], float mx) -> float {
-        float ex[EPER];
+        float d[EPER], ex[EPER];
 #pragma unroll
-        for (int r = 0; r < EPER; ++r) ex[r] = xb_expf(x[r] - mx);
+        for (int r = 0; r < EPER; ++r) d[r] = x[r] - mx;
+        xb_exp_n<EPER>(d, ex);
         float s;
         if constexpr (LPS == 1) {
             s = ex[0];
@@ -453,7 +562,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 float *qs = sQ + (t & 1) * cpad;
                 const float *b1 = sA + ((t + 1) & 1) * S;
                 const float *m1 = sX + ((t + 1) & 1) * S;
-                float y[EPER];
+                float u[EPER], y[EPER], mjv[EPER];
                 float mx = -__builtin_inff(), mm = -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < EPER; ++r) {
@@ -461,19 +570,44 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                     float mv = m[midx[r]];
                     if (!HB && r == 0) mv = stay0 ? blank : mv;
                     const float bj = b1[dstj[r]];
-                    const float mj = m1[dstj[r]];
-                    const float xx = ((a0 + mv) + bj) - logZ;
-                    const float q = xb_logf(xb_expf(xx) + 1e-8f);
-                    y[r] = val ? mv + bj : -__builtin_inff();
-                    if (val) {
+                    mjv[r] = m1[dstj[r]];
+                    u[r] = ((a0 + mv) + bj) - logZ;              // log-posterior of the edge
+                    y[r] = val ? mv + bj : -__builtin_inff();    // beta recursion term
+                    mx = maxf(mx, y[r]);
+                }
+                if (LPS == 2) mx = pair_max(mx);
+                // one two-wide exp per edge: (posterior, logsumexp term)
+                float P[EPER], ex[EPER];
+#pragma unroll
+                for (int r = 0; r < EPER; ++r) {
+                    const f32x2 v = xb_expf2((f32x2){u[r], y[r] - mx});
+                    P[r] = v.x;
+                    ex[r] = v.y;
+                }
+                float sm;
+                if constexpr (LPS == 1) {
+                    sm = ex[0];
+#pragma unroll
+                    for (int r = 1; r < EPER; ++r) sm += ex[r];
+                } else {
+                    sm = pair_sum_ordered<E>(ex);
+                }
+                // the EPER logs of Q = log(P + 1e-8) and the log of the logsumexp, two at a time
+                float la[EPER + 1], lo[EPER + 1];
+#pragma unroll
+                for (int r = 0; r < EPER; ++r) la[r] = P[r] + 1e-8f;
+                la[EPER] = sm;
+                xb_log_n<EPER + 1>(la, lo);
+                const float bv = mx + lo[EPER];
+#pragma unroll
+                for (int r = 0; r < EPER; ++r) {
+                    if (r < kcnt) {
                         const int k = (r == 0 && stay0) ? 0 : kk;
-                        if (act) qs[dstj[r] * E + k] = q;
-                        mx = maxf(mx, y[r]);
-                        mm = maxf(mm, q + mj);
+                        if (act) qs[dstj[r] * E + k] = lo[r];
+                        mm = maxf(mm, lo[r] + mjv[r]);
                     }
                 }
-                if (LPS == 2) { mx = pair_max(mx); mm = pair_max(mm); }
-                const float bv = lse_tail(y, mx);
+                if (LPS == 2) mm = pair_max(mm);
                 if (ph == 0 && act) {
                     sA[(t & 1) * S + i] = bv;
                     sX[(t & 1) * S + i] = mm;
@@ -523,7 +657,10 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             }
         };
         float aown = 0.0f;
+        static_assert(RDEPTH % 4 == 0, "the arg-max reductions are batched four steps at a time");
         for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
+          float bestv[RDEPTH];
+          int bestc[RDEPTH];
 #pragma unroll
           for (int d = 0; d < RDEPTH; ++d) {
             const int t = t0 + d;                                // >= T in the padding iterations
@@ -538,13 +675,15 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             }
             lds_barrier();
             // every 64 steps one wave (taking turns) finalises the 64 steps before this one: their partials were all
-            // written before this barrier, and the ring slots being rewritten meanwhile are 64 steps away
+            // written before this barrier, and the ring slots being rewritten meanwhile are at least 56 steps away
             if ((t & 63) == 0 && t > 0 && t <= T && wave == ((t >> 6) % NW)) finalise(t - 64);
+            bestv[d] = -__builtin_inff();
+            bestc[d] = 0x7fffffff;
             if (t < T) {                                         // block-uniform
                 const float *am = sX + (t & 1) * S;
                 float mm = -__builtin_inff();
                 float best = -__builtin_inff();
-                int bestc = 0x7fffffff;
+                int bc = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < EPER; ++r) {
                     const float Q = (LPS == 1 || ph == 0) ? qv[r] : qv[r + SH < EPER ? r + SH : EPER - 1];
@@ -554,23 +693,34 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                     if (r < kcnt) {
                         mm = maxf(mm, Q + av);
                         const float scv = (av + Q) + m1j;
-                        if (scv > best) { best = scv; bestc = j * E + k0 + r; }   // increasing flat index
+                        if (scv > best) { best = scv; bc = j * E + k0 + r; }   // increasing flat index
                     }
                 }
                 if (LPS == 2) mm = pair_max(mm);
                 aown = mm;
                 if (ph == 0 && act) sX[((t + 1) & 1) * S + tpos] = mm;
-                // arg-max over the workgroup's edges: lanes are in flat-index order (state major, the two halves of a
-                // state on adjacent lanes), each lane holds its lowest-index maximiser, so the lowest lane that attains
-                // the wave maximum holds the wave's lowest flat index
-                if (!act) best = -__builtin_inff();
-                const float wmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max63(best)), 63));
-                const unsigned long long hit = __ballot(best == wmx);
-                const int wl = __builtin_amdgcn_readfirstlane(hit ? (int)__builtin_ctzll(hit) : 0);
-                const int wc = __builtin_amdgcn_readlane(bestc, wl);
-                if (lane == 0) {
-                    sRv[(t & (LRING - 1)) * NW + wave] = wmx;
-                    sRi[(t & (LRING - 1)) * NW + wave] = wc;
+                bestv[d] = act ? best : -__builtin_inff();
+                bestc[d] = bc;
+            }
+            // Arg-max over the workgroup's edges, four steps at a time (the four reduction chains interleave; done per
+            // step, the serial chain would be the longest part of the step).  Lanes are in flat-index order (state major,
+            // the two halves of a state on adjacent lanes) and each lane holds its lowest-index maximiser, so the lowest
+            // lane that attains the wave maximum holds the wave's lowest flat index.
+            if ((d & 3) == 3) {
+                float w0 = bestv[d - 3], w1 = bestv[d - 2], w2 = bestv[d - 1], w3 = bestv[d];
+                wave_max63_x4(w0, w1, w2, w3);
+                const float wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t - 3 + q;
+                    const float wmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv[q]), 63));
+                    const unsigned long long hit = __ballot(bestv[d - 3 + q] == wmx);
+                    const int wl = __builtin_amdgcn_readfirstlane(hit ? (int)__builtin_ctzll(hit) : 0);
+                    const int wc = __builtin_amdgcn_readlane(bestc[d - 3 + q], wl);
+                    if (lane == 0 && tq < T) {
+                        sRv[(tq & (LRING - 1)) * NW + wave] = wmx;
+                        sRi[(tq & (LRING - 1)) * NW + wave] = wc;
+                    }
                 }
             }
           }

@@ -11,7 +11,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier"]
+__all__ = ["init_from_env", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier",
+           "DeferredGather"]
 
 
 def init_from_env(backend=None):
@@ -108,3 +109,57 @@ def gather_packed(seq, lens):
     dist.all_gather_into_tensor(out_s, seq.contiguous())
     dist.all_gather_into_tensor(out_l, lens.contiguous())
     return out_s.view((w,) + tuple(seq.shape)), out_l.view((w,) + tuple(lens.shape))
+
+
+class DeferredGather:
+    """
+    The path's one exchange, taken off the compute stream: batch k's (seq, lens) are gathered while batch k+1 is being
+    computed.  `submit` hands in the buffers of the batch just enqueued together with an event that fires when they are
+    complete, starts the gather of the PREVIOUS submission on a side stream behind that submission's event, and returns
+    the gathered result of the previous submission (None for the first call); `flush` gathers the last one.  After
+    `submit(k)` returned, `consumed(k - 1)` is the event to wait for before batch k - 1's buffers are written again
+    (two buffer sets in rotation: wait for it just before enqueueing batch k + 1).
+    CPU tensors (gloo tests) take the same route without streams or events.
+    """
+
+    def __init__(self):
+        self._pending = None            # (seq, lens, ready_event, ticket)
+        self._consumed = {}
+        self._ticket = 0
+        self._side = None
+
+    def _gather(self, seq, lens, ready):
+        if seq.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=seq.device)
+            if ready is not None:
+                self._side.wait_event(ready)
+            with torch.cuda.stream(self._side):
+                out = gather_packed(seq, lens)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            return out, done
+        return gather_packed(seq, lens), None
+
+    def submit(self, seq, lens, ready_event=None):
+        prev, out = self._pending, None
+        self._pending = (seq, lens, ready_event, self._ticket)
+        self._ticket += 1
+        if prev is not None:
+            out, done = self._gather(prev[0], prev[1], prev[2])
+            self._consumed[prev[3]] = done
+            self._consumed.pop(prev[3] - 2, None)
+        return out
+
+    def consumed(self, ticket):
+        """Event recorded behind the gather of submission `ticket` (None on CPU or if it has not been gathered)."""
+        return self._consumed.get(ticket)
+
+    def flush(self):
+        prev, self._pending = self._pending, None
+        if prev is None:
+            return None
+        out, done = self._gather(prev[0], prev[1], prev[2])
+        if done is not None:
+            done.synchronize()
+        return out
