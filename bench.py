@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--lstm-mode", type=int, default=0)
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the deferred side-stream gather plumbing even with one rank (harness self-test)")
     args = ap.parse_args()
 
     import torch
@@ -118,7 +120,7 @@ def main():
     # two output buffer sets in rotation: batch k's sequences are gathered (side stream) while batch k+1 computes
     d_seq = [torch.empty((N, T), dtype=torch.int8, device=dev) for _ in range(2)]
     d_len = [torch.empty((N,), dtype=torch.int32, device=dev) for _ in range(2)]
-    gather = xdist.DeferredGather() if world > 1 else None
+    gather = xdist.DeferredGather() if (world > 1 or args.force_gather) else None
     state = {"k": 0}
 
     def step():

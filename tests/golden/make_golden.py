@@ -161,6 +161,30 @@ def seeded_state_dict(model_state, seed):
     return out
 
 
+def make_revcomp():
+    """(10) CTC_CRF.reverse_complement (crf/model.py:78-90, pure torch, reference code): index maps for nb 4/5/6 and
+    state_len 2/3.  The input holds its own flat index, so the output IS the gather map out[t, n, c] = in[T-1-t, n, map[c]]."""
+    _install_placeholders()
+    crfpkg = types.ModuleType("bonito.crf")
+    crfpkg.__path__ = [REF + "/crf"]
+    sys.modules["bonito.crf"] = crfpkg
+    if "bonito.nn" not in sys.modules:
+        _load("bonito.nn", REF + "/nn.py")
+    crf = sys.modules.get("bonito.crf.model") or _load("bonito.crf.model", REF + "/crf/model.py")
+    out = {}
+    for nb in (4, 5, 6):
+        for sl in (2, 3):
+            labels = ["N", "A", "C", "G", "T", "X", "Y"][:nb + 1]
+            sd = crf.CTC_CRF(sl, labels)
+            C = (nb + 1) * nb ** sl
+            T, N = 3, 2
+            x = torch.arange(T * N * C, dtype=torch.float32).reshape(T, N, C)
+            y = sd.reverse_complement(x).numpy().astype(np.int64)
+            out["nb%d_sl%d" % (nb, sl)] = y
+    np.savez_compressed(os.path.join(OUT, "revcomp.npz"), **out)
+    print("revcomp.npz written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -347,4 +371,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "revcomp":      # regenerate only that fixture
+        make_revcomp()
+    else:
+        main()
+        make_revcomp()

@@ -165,3 +165,17 @@ def test_cli_argparser_defaults():
     a = p.parse_args(["m", "r", "--batch", "98", "--read-ids", "ids.tsv"])      # prefix abbreviation, eval_model.sh:29
     assert a.batchsize == 98 and a.device == "cuda" and a.seed == 25 and a.weights == "0"
     assert a.chunksize is None and a.overlap is None and a.use_koi is True and a.quantize is None
+
+
+def test_reverse_complement_matches_reference():
+    """CTC_CRF.reverse_complement (crf/model.py:78-90) against gather maps recorded from the reference's own code."""
+    from xna_basecaller_amd.crf.model import CTC_CRF
+    z = np.load(os.path.join(GOLDEN, "revcomp.npz"))
+    for nb in (4, 5, 6):
+        for sl in (2, 3):
+            sd = CTC_CRF(sl, list("NACGTXY"[:nb + 1]))
+            C = (nb + 1) * nb ** sl
+            x = np.arange(3 * 2 * C, dtype=np.float32).reshape(3, 2, C)
+            got = sd.reverse_complement(x)
+            assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"]
+            assert np.array_equal(got.astype(np.int64), z["nb%d_sl%d" % (nb, sl)])

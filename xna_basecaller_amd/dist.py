@@ -102,7 +102,7 @@ def gather_packed(seq, lens):
     """
     w = world_size()
     if w == 1:
-        return seq[None], lens[None]
+        return seq[None].clone(), lens[None].clone()       # a copy, like the collective: the inputs may be reused
     # all_gather_into_tensor concatenates along dim 0 (the layout both gloo and nccl accept)
     out_s = torch.empty((w * seq.shape[0],) + tuple(seq.shape[1:]), dtype=seq.dtype, device=seq.device)
     out_l = torch.empty((w * lens.shape[0],) + tuple(lens.shape[1:]), dtype=lens.dtype, device=lens.device)
