@@ -128,6 +128,18 @@ XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const cha
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet,
                                   int8_t *d_seq, int32_t *d_seq_len);
 
+/*
+ * The same operator for a host pipeline that keeps the device busy (crf/basecall.py:96-119: the reference overlaps its
+ * stages with threads and bounded queues; here the overlap is two batches in flight on the device).
+ * xb_submit_chunks copies `signal` (n, L) into pinned staging of `slot` (0 or 1), enqueues H2D on a copy stream, the
+ * fused encode + decode, and the D2H of the results into pinned staging, and returns without waiting.
+ * xb_collect_chunks waits for that slot's batch only and copies seq (n, T) / seq_len (n) out.  Typical use: submit
+ * batch k+1 into the other slot, then collect batch k -- results arrive one batch late, in order.
+ * A slot must be collected before it is submitted again (XB_ERR_STATE otherwise).
+ */
+XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, const char *alphabet);
+XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_len);
+
 XB_API int xb_synchronize(xb_ctx *ctx);
 
 /*

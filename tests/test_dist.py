@@ -54,6 +54,34 @@ for k, (s, l) in enumerate(outs):
     assert s.shape == (2, 2, 4) and l.shape == (2, 2)
     assert s[0, 0, 0].item() == 10 * k and s[1, 1, 3].item() == 10 * k + 1
     assert l[0].tolist() == [k, 0] and l[1].tolist() == [k, 1]
+# the CLI's windowed gather of called reads to rank 0 (cli/basecaller.py:_gathered_results)
+from xna_basecaller_amd.cli.basecaller import _gathered_results, READ_FIELDS
+class FakeRead:
+    def __init__(self, i):
+        self.index = i
+        for k in READ_FIELDS: setattr(self, k, "%s%d" % (k[:2], i))
+        self.signal = np.zeros(100 + i, np.float32)
+    def tagdata(self): return ["mx:i:%d" % self.index]
+class FakeLoader: total = 23
+def local(fail_at=None):
+    for i in range(rank, 23, 2):
+        if fail_at is not None and i == fail_at: raise ValueError("boom at %d" % i)
+        yield FakeRead(i), {"sequence": "ACGT"[: 1 + i % 4], "qstring": "O" * (1 + i % 4)}
+got = list(_gathered_results(local(), FakeLoader, rank, world, window=3))
+if rank == 0:
+    assert [r.read_id for r, _ in got] == ["re%d" % i for i in range(23)]
+    assert [len(r.signal) for r, _ in got] == [100 + i for i in range(23)] and got[5][0].tagdata() == ["mx:i:5"]
+    assert all(res["sequence"] == "ACGT"[: 1 + i % 4] for i, (_, res) in enumerate(got))
+else:
+    assert got == []
+# a rank that fails mid-way: nobody hangs, rank 0 and the failing rank both raise
+try:
+    list(_gathered_results(local(fail_at=9), FakeLoader, rank, world, window=3))
+    raised = False
+except (RuntimeError, ValueError) as e:
+    raised = True
+    assert "boom at 9" in str(e)
+assert raised == (rank in (0, 1))
 xd.barrier()
 print("rank", rank, "ok")
 '''
@@ -75,7 +103,12 @@ def test_shard_and_gather_world2(tmp_path):
                    MASTER_PORT=port, XB_ROOT=ROOT)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    try:
+        outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    finally:
+        for p in procs:                      # never leave a blocked rank behind
+            if p.poll() is None:
+                p.kill()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o

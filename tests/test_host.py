@@ -158,6 +158,32 @@ def test_writer_fastq_and_summary(tmp_path):
     assert rows[0].split("\t")[:3] == ["filename", "read_id", "run_id"] and len(rows) == 3
 
 
+def test_summary_table_bytes_follow_the_csv_dialect(tmp_path):
+    """The reference writes the summary with csv.writer(delimiter='\\t') on a newline='' file (io.py:322-356): CRLF line
+    ends, minimal quoting, floats as str(); an existing file is appended to without a second header."""
+    import csv
+    rows = [{"filename": "a b.fast5", "read_id": "r\t1", "run_id": 'q"x', "channel": "12", "mux": 3, "start_time": 1.5,
+             "duration": 0.25, "template_start": 1.75, "template_duration": 1e-05, "sequence_length_template": 7,
+             "mean_qscore_template": 40.0},
+            {"filename": "b.fast5", "read_id": "r2", "run_id": "run", "channel": 1, "mux": 1, "start_time": 0.0,
+             "duration": 2.0, "template_start": 0.1, "template_duration": 1.9, "sequence_length_template": 120,
+             "mean_qscore_template": 39.99999999999999}]
+    mine, ref = tmp_path / "mine.tsv", tmp_path / "ref.tsv"
+    for half in (rows[:1], rows[1:]):                   # second pass appends to the existing files
+        with xio.SummaryTable(mine) as t:
+            for r in half:
+                t.append(r)
+        new = not ref.exists()
+        with open(ref, "a", newline="") as fh:
+            w = csv.writer(fh, delimiter="\t")
+            if new:
+                w.writerow(list(xio.SUMMARY_COLUMNS))
+            for r in half:
+                w.writerow([r.get(k, "-") for k in xio.SUMMARY_COLUMNS])
+    assert mine.read_bytes() == ref.read_bytes()
+    assert mine.read_bytes().count(b"\r\n") == 3
+
+
 def test_cli_argparser_defaults():
     from xna_basecaller_amd.cli.basecaller import argparser
     from argparse import ArgumentParser

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""
+End-to-end throughput of the drop-in CLI on synthetic reads (run on the GPU box):
+writes a model directory (shipped geometry: features 768, 6-base CRF, seeded weights, chunksize 10000, batch 512) and a
+signal bundle of READS reads x ~SAMPLES raw samples under /tmp, runs `python -m xna_basecaller_amd basecaller` with
+stdout redirected to a .fastq file and reports the CLI's own "> samples per second" (cli/basecaller.py:153-161).
+Usage: python tools/cli_e2e.py [--reads 2000] [--samples 50000] [--batch 512]
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=2000)
+    ap.add_argument("--samples", type=int, default=50000)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--chunksize", type=int, default=10000)
+    ap.add_argument("--features", type=int, default=768)
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from xna_basecaller_amd import reads as xreads, toml_lite
+    from xna_basecaller_amd.synthetic import seeded_weights
+
+    work = tempfile.mkdtemp(prefix="xb_e2e_", dir="/tmp")
+    model_dir = os.path.join(work, "xna_synth@v1")
+    reads_dir = os.path.join(work, "reads")
+    os.makedirs(model_dir)
+    os.makedirs(reads_dir)
+    cfg = {"global_norm": {"state_len": 3}, "qscore": {"bias": 0.3498, "scale": 0.9722}, "input": {"features": 1},
+           "model": {"package": "bonito.crf"}, "labels": {"labels": list("NACGTXY")},
+           "encoder": {"stride": 5, "activation": "swish", "features": args.features, "winlen": 19, "scale": 5.0,
+                       "rnn_type": "lstm", "blank_score": 2.0},
+           "basecaller": {"batchsize": args.batch, "chunksize": args.chunksize, "overlap": 500}}
+    with open(os.path.join(model_dir, "config.toml"), "w") as fh:
+        fh.write(toml_lite.dumps(cfg))
+    sd = seeded_weights(args.features, 6)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(model_dir, "weights_1.tar"))
+
+    rng = np.random.default_rng(3)
+    t0 = time.time()
+    per_file = 250
+    for f0 in range(0, args.reads, per_file):
+        recs = []
+        for i in range(f0, min(f0 + per_file, args.reads)):
+            length = int(args.samples * rng.uniform(0.6, 1.4))
+            base = rng.normal(90.0, 12.0, length)
+            lead = int(rng.integers(300, 900))
+            base[:lead] = rng.normal(140.0, 3.0, lead)
+            raw = np.round(base * 8.0).astype(np.int16)
+            recs.append((raw, dict(read_id="read-%06d" % i, range=1443.03, digitisation=8192.0, offset=10,
+                                   sampling_rate=4000.0, run_id="runX", channel_number=str(1 + i % 512),
+                                   start_mux=1 + i % 4, read_number=i, start_time=4000 * i, duration=length,
+                                   exp_start_time="2021-06-01T10:00:00Z")))
+        xreads.write_bundle(os.path.join(reads_dir, "batch%04d.xsig.npz" % (f0 // per_file)), recs)
+    print("wrote %d reads in %.1f s" % (args.reads, time.time() - t0), flush=True)
+
+    out = os.path.join(work, "calls.fastq")
+    t0 = time.time()
+    with open(out, "w") as fh:
+        r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir], cwd=ROOT,
+                           stdout=fh, stderr=subprocess.PIPE)
+    wall = time.time() - t0
+    err = r.stderr.decode()
+    print(err[-1200:])
+    print("cli wall (incl. start-up and model load): %.1f s, rc %d, fastq %d bytes" % (wall, r.returncode, os.path.getsize(out)))
+    if not args.keep:
+        shutil.rmtree(work, ignore_errors=True)
+    sys.exit(r.returncode)
+
+
+if __name__ == "__main__":
+    main()

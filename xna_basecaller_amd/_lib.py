@@ -21,6 +21,7 @@ EXPORTS = [
     "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev",
     "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
     "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
+    "xb_submit_chunks", "xb_collect_chunks",
 ]
 
 
@@ -70,6 +71,8 @@ def load():
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
+    lib.xb_submit_chunks.argtypes = [vp, ip, vp, ip, C.c_char_p]
+    lib.xb_collect_chunks.argtypes = [vp, ip, vp, vp]
     lib.xb_result_stream.argtypes = [vp]
     lib.xb_result_stream.restype = C.c_void_p
     lib.xb_set_profiling.argtypes = [vp, ip]
@@ -167,6 +170,19 @@ class Context:
         lens = np.empty((n,), dtype=np.int32)
         self._check(self.lib.xb_basecall_chunks(self.h, signal.ctypes.data, n, "".join(alphabet).encode(),
                                                 seq.ctypes.data, lens.ctypes.data))
+        return seq, lens
+
+    # ---- host pipeline: two batches in flight (xb_submit_chunks / xb_collect_chunks) ----------
+    def submit_chunks(self, slot, signal, alphabet):
+        signal = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1, self.chunk_len)
+        self._check(self.lib.xb_submit_chunks(self.h, int(slot), signal.ctypes.data, signal.shape[0],
+                                              "".join(alphabet).encode()))
+        return signal.shape[0]
+
+    def collect_chunks(self, slot, n):
+        seq = np.empty((n, self.T), dtype=np.int8)
+        lens = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.xb_collect_chunks(self.h, int(slot), seq.ctypes.data, lens.ctypes.data))
         return seq, lens
 
     # ---- device-pointer operators (pointers are ints, e.g. torch data_ptr()) -----------------

@@ -11,7 +11,6 @@ import os
 import sys
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 from datetime import timedelta
-from itertools import islice as take
 from time import perf_counter
 
 import numpy as np
@@ -22,9 +21,81 @@ from ..reads import get_reads
 from ..util import column_to_set, init, load_model, load_symbol
 
 
+READ_FIELDS = ("read_id", "run_id", "filename", "channel", "mux", "start", "duration", "template_start",
+               "template_duration")
+
+
+class _CalledRead:
+    """What the writer needs of a read that was basecalled on another rank: its metadata and length, not its signal."""
+
+    def __init__(self, fields, tags, n_samples):
+        for k, v in zip(READ_FIELDS, fields):
+            setattr(self, k, v)
+        self._tags = tags
+        self.signal = np.broadcast_to(np.float32(0), (n_samples,))     # len() only; no memory behind it
+
+    def tagdata(self):
+        return self._tags
+
+
+def _gathered_results(results, loader, rank, world, window=256):
+    """
+    Multi-GPU: every rank basecalls its shard (reads i % world == rank); rank 0 receives (index, metadata, sequence)
+    of all ranks in windows of `window` reads per rank and yields them in global read order, so nothing but metadata
+    and called strings is kept, output starts while later windows are still being basecalled, and the collective is
+    entered the same number of times by every rank.  A rank that fails keeps entering the remaining collectives with
+    an error marker (its peers are never left blocked), then re-raises; rank 0 raises once it has seen the marker.
+    """
+    import torch.distributed as tdist
+    n_windows = (loader.total + window * world - 1) // (window * world) if loader.total else 0
+    it = iter(results)
+    failure = None
+    held = None
+    for w in range(n_windows):
+        hi = (w + 1) * window * world                   # global indices below `hi` belong to this window
+        batch = []
+        while failure is None:
+            try:
+                item = held if held is not None else next(it)
+                held = None
+            except StopIteration:
+                break
+            except BaseException as e:                   # noqa: BLE001 -- carried to rank 0, re-raised below
+                failure = e
+                break
+            read, res = item
+            if read.index >= hi:
+                held = item
+                break
+            batch.append((read.index, tuple(getattr(read, k) for k in READ_FIELDS), read.tagdata(), len(read.signal),
+                          res["sequence"], res["qstring"]))
+        payload = ("error", repr(failure)) if failure is not None else ("ok", batch)
+        gathered = [None] * world if rank == 0 else None
+        tdist.gather_object(payload, gathered, dst=0)
+        if rank == 0 and failure is None:
+            bad = [p[1] for p in gathered if p[0] == "error"]
+            if bad:
+                # keep entering the remaining collectives (the other ranks do), raise at the end
+                failure = RuntimeError("a rank failed while basecalling: %s" % "; ".join(bad))
+                continue
+            merged = sorted((rec for p in gathered for rec in p[1]), key=lambda rec: rec[0])
+            for _, fields, tags, n_samples, seq, qstring in merged:
+                yield _CalledRead(fields, tags, n_samples), {"sequence": seq, "qstring": qstring}
+    if failure is not None:
+        raise failure
+
+
 def main(args):
-    init(args.seed, args.device)
     rank, world = xdist.init_from_env()
+    if args.read_ids is not None and not os.path.isfile(args.read_ids):
+        raise FileNotFoundError(args.read_ids)
+    # the reader pool (8 worker processes, cli/basecaller.py:107-111) is forked BEFORE anything touches the GPU; under
+    # torchrun every rank only ever loads its own shard of the reads
+    reads = get_reads(args.reads_directory, n_proc=8, recursive=args.recursive,
+                      read_ids=column_to_set(args.read_ids), skip=args.skip, limit=args.max_reads,
+                      shard=(rank, world) if world > 1 else None)
+
+    init(args.seed, args.device)
     device = args.device
     if world > 1 and device == "cuda":
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", rank))
@@ -53,55 +124,19 @@ def main(args):
     if fmt.name != "fastq":
         sys.stderr.write("> error: only FASTQ output is implemented (redirect stdout to *.fastq)\n")
         exit(1)
-    if args.read_ids is not None and not os.path.isfile(args.read_ids):
-        raise FileNotFoundError(args.read_ids)
 
-    reads = get_reads(args.reads_directory, n_proc=8, recursive=args.recursive,
-                      read_ids=column_to_set(args.read_ids), skip=args.skip)
-    if args.max_reads:
-        reads = take(reads, args.max_reads)
-
-    index_of = {}
-    if world > 1:
-        def local_reads():
-            for i, read in xdist.shard(reads, rank, world):
-                index_of[id(read)] = i
-                yield read
-        reads_in = local_reads()
-    else:
-        reads_in = reads
-
-    results = basecall(model, reads_in, reverse=args.revcomp,
+    results = basecall(model, reads, reverse=args.revcomp,
                        batchsize=model.config["basecaller"]["batchsize"],
                        chunksize=model.config["basecaller"]["chunksize"],
                        overlap=model.config["basecaller"]["overlap"])
 
     t0 = perf_counter()
     if world > 1:
-        # every rank basecalls its shard; one RCCL gather brings (index, read, sequence) to rank 0
-        local, by_index = [], {}
-        for read, res in results:
-            i = index_of[id(read)]
-            local.append((i, read.read_id, res["sequence"], res["qstring"]))
-            by_index[i] = read
-        meta = [(i, r.read_id, r.run_id, r.filename, str(r.channel), int(r.mux), float(r.start), float(r.duration),
-                 float(r.template_start), float(r.template_duration), r.tagdata(), len(r.signal))
-                for i, r in by_index.items()]
-        import torch.distributed as tdist
-        metas = [None] * world
-        tdist.all_gather_object(metas, meta)
-        merged = xdist.gather_called(local, dst=0)
+        results = _gathered_results(results, reads, rank, world)
         if rank != 0:
+            for _ in results:                           # drives the local pipeline and the collectives
+                pass
             return
-        from ..reads import SyntheticRead
-        lookup = {}
-        for m in (x for ms in metas for x in ms):
-            r = SyntheticRead(m[1], np.zeros(m[11], np.float32), run_id=m[2], filename=m[3], channel=m[4], mux=m[5],
-                              start=m[6])
-            r.duration, r.template_start, r.template_duration = m[7], m[8], m[9]
-            r.tagdata = (lambda tags: (lambda: tags))(m[10])
-            lookup[m[0]] = r
-        results = ((lookup[i], {"sequence": seq, "qstring": q}) for i, _, seq, q in merged)
 
     writer = Writer(fmt.mode, results, aligner=None, group_key=args.model_directory)
     writer.start()

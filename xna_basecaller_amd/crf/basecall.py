@@ -64,12 +64,42 @@ def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offse
         sequence, _ = ctx.decode(scores, model.alphabet)
     else:
         sequence, _ = model.basecall_chunks(batch)
+    return _scores_dict(sequence)
+
+
+def _scores_dict(sequence):
+    """The reference's result layout around the left-packed ASCII rows: dummy quality 'O', no moves."""
     qstring = np.where(sequence != 0, np.int8(ord("O")), np.int8(0)).astype(np.int8)
     return {
         "qstring": qstring,
         "sequence": sequence,
         "moves": np.zeros(sequence.shape, dtype=bool),
     }
+
+
+def compute_scores_pipelined(model, batches, reverse=False):
+    """
+    compute_scores over a stream of (key, batch) with TWO batches in flight on the device: batch k+1 is submitted
+    (pinned staging, H2D on a copy stream, fused kernels, D2H) before batch k's result is waited for, so the GPU
+    never idles while the host unpacks results.  Results come out in input order, one batch late.
+    """
+    if reverse or not model.encoder[-1].expand_blanks:
+        for key, batch in batches:                       # decode of host-side reverse-complemented scores: synchronous
+            yield key, compute_scores(model, batch, reverse=reverse)
+        return
+    pending, slot = None, 0
+    for key, batch in batches:
+        shape = np.asarray(batch).shape
+        if pending is not None and not model.context_is_current(shape[-1], shape[0]):
+            yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])     # drain before the context is rebuilt
+            pending = None
+        handle = model.submit_chunks(slot, batch)
+        slot ^= 1
+        if pending is not None:
+            yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])
+        pending = (key, handle)
+    if pending is not None:
+        yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])
 
 
 def to_str(x, encoding="ascii"):
@@ -97,9 +127,7 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
         for read in reads
     )
     batches = thread_iter(batchify(chunks, batchsize=batchsize))
-    scores = thread_iter(
-        (key, compute_scores(model, batch, reverse=reverse)) for key, batch in batches
-    )
+    scores = thread_iter(compute_scores_pipelined(model, batches, reverse=reverse))
     results = thread_iter(
         (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
         for ((read, start, end), sc) in unbatchify(scores)

@@ -167,10 +167,17 @@ class Model(torch.nn.Module):
         self._ctx, self._ctx_key = None, None
 
     # ---- device context -------------------------------------------------------------------
-    def context(self, chunk_len, batch):
-        """The xb_ctx for this chunk length; rebuilt when the geometry grows."""
+    def context_is_current(self, chunk_len, batch):
+        """True when context(chunk_len, batch) would hand back the live context (nothing in flight is lost)."""
         key = (self._device, int(chunk_len), self.precision)
-        if self._ctx is None or self._ctx_key != key or batch > self._ctx.max_batch:
+        return self._ctx is not None and self._ctx_key == key and batch <= self._ctx.max_batch
+
+    def context(self, chunk_len, batch):
+        """The xb_ctx for this chunk length; rebuilt when the geometry grows.  Sized for at least the configured
+        basecaller batchsize so that a short first batch does not force a rebuild on the next one."""
+        key = (self._device, int(chunk_len), self.precision)
+        if not self.context_is_current(chunk_len, batch):
+            batch = max(int(batch), int(self.config.get("basecaller", {}).get("batchsize", 0) or 0))
             self._drop_context()
             last = self.encoder[-1]
             ctx = _lib.Context(self._device, self.seqdist.n_base, self.seqdist.state_len, self._features,
@@ -215,3 +222,15 @@ class Model(torch.nn.Module):
         sig = self._as_signal(batch)
         ctx = self.context(sig.shape[1], sig.shape[0])
         return ctx.basecall_chunks(sig, self.alphabet)
+
+    def submit_chunks(self, slot, batch):
+        """Enqueue the fused encode + decode of a (N,1,L) batch in pipeline slot 0/1 without waiting; returns a handle
+        for collect_chunks.  The caller keeps at most one handle per slot in flight."""
+        sig = self._as_signal(batch)
+        ctx = self.context(sig.shape[1], sig.shape[0])
+        return ctx, slot, ctx.submit_chunks(slot, sig, self.alphabet)
+
+    @staticmethod
+    def collect_chunks(handle):
+        ctx, slot, n = handle
+        return ctx.collect_chunks(slot, n)

@@ -43,6 +43,16 @@ struct xb_ctx {
     bool dec_pending[2] = {};
     unsigned batch_idx = 0;
     hipStream_t result_stream = nullptr;   // stream that produces the outputs of the most recent *_dev call
+    // host pipeline (xb_submit_chunks / xb_collect_chunks): two slots of pinned staging + device buffers
+    struct Slot {
+        float *h_signal = nullptr, *d_signal = nullptr;
+        int8_t *h_seq = nullptr, *d_seq = nullptr;
+        int32_t *h_len = nullptr, *d_len = nullptr;
+        hipEvent_t h2d = nullptr, done = nullptr;
+        int n = 0;
+        bool busy = false;
+    } slots[2];
+    hipStream_t stream_copy = nullptr;     // H2D of the next batch beside the compute of the current one
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
     size_t dep_next = 0;
     int overlap = 1, time_slabs = 16;   // XB_OVERLAP / XB_TIME_SLABS (upper bound; a slab is at least 125 steps)
@@ -598,6 +608,14 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     for (auto &e : ctx->dec_done) if (e) (void)hipEventDestroy(e);
+    for (auto &sl : ctx->slots) {
+        if (sl.h_signal) (void)hipHostFree(sl.h_signal);
+        if (sl.h_seq) (void)hipHostFree(sl.h_seq);
+        if (sl.h_len) (void)hipHostFree(sl.h_len);
+        if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); }
     for (auto &e : ctx->deps) (void)hipEventDestroy(e);
     for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto &b : ctx->bufs) hipFree(b.p);
@@ -800,6 +818,71 @@ XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const cha
     XB_HIP(ctx, hipMemcpyAsync(seq, ctx->seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, ctx->stream));
     if (seq_len) XB_HIP(ctx, hipMemcpyAsync(seq_len, ctx->seq_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return xb_synchronize(ctx);
+}
+
+// lazily created: most contexts (tests, bench) never use the host pipeline
+static int ensure_slot(xb_ctx *ctx, int slot)
+{
+    xb_ctx::Slot &sl = ctx->slots[slot];
+    if (sl.h_signal) return XB_OK;
+    const size_t N = ctx->cfg.max_batch, L = ctx->cfg.chunk_len, T = ctx->T;
+    if (!ctx->stream_copy) XB_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+    XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_signal), sizeof(float) * N * L, hipHostMallocDefault));
+    XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_seq), N * T, hipHostMallocDefault));
+    XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_len), sizeof(int32_t) * N, hipHostMallocDefault));
+    int rc = dev_alloc(ctx, &sl.d_signal, N * L);
+    rc = rc ? rc : dev_alloc(ctx, &sl.d_seq, N * T);
+    rc = rc ? rc : dev_alloc(ctx, &sl.d_len, N);
+    if (rc) return rc;
+    XB_HIP(ctx, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+    XB_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    return XB_OK;
+}
+
+XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, const char *alphabet)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (slot < 0 || slot > 1 || !signal || !alphabet) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_slot(ctx, slot))) return rc;
+    xb_ctx::Slot &sl = ctx->slots[slot];
+    if (sl.busy) return fail(ctx, XB_ERR_STATE, "slot %d was submitted and not collected", slot);
+    const size_t bytes = sizeof(float) * (size_t)n * ctx->cfg.chunk_len;
+    memcpy(sl.h_signal, signal, bytes);                       // the caller's buffer is free again on return
+    XB_HIP(ctx, hipMemcpyAsync(sl.d_signal, sl.h_signal, bytes, hipMemcpyHostToDevice, ctx->stream_copy));
+    XB_HIP(ctx, hipEventRecord(sl.h2d, ctx->stream_copy));
+    XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.h2d, 0));
+    rc = xb_basecall_chunks_dev(ctx, sl.d_signal, n, alphabet, sl.d_seq, sl.d_len);
+    if (rc) return rc;
+    hipStream_t rs = ctx->result_stream ? ctx->result_stream : ctx->stream;
+    XB_HIP(ctx, hipMemcpyAsync(sl.h_seq, sl.d_seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, rs));
+    XB_HIP(ctx, hipMemcpyAsync(sl.h_len, sl.d_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, rs));
+    XB_HIP(ctx, hipEventRecord(sl.done, rs));
+    sl.n = n;
+    sl.busy = true;
+    return XB_OK;
+}
+
+XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_len)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (slot < 0 || slot > 1 || !seq) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
+    xb_ctx::Slot &sl = ctx->slots[slot];
+    if (!sl.busy) return fail(ctx, XB_ERR_STATE, "slot %d has nothing in flight", slot);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    XB_HIP(ctx, hipEventSynchronize(sl.done));
+    sl.busy = false;
+    memcpy(seq, sl.h_seq, (size_t)sl.n * ctx->T);
+    if (seq_len) memcpy(seq_len, sl.h_len, sizeof(int32_t) * (size_t)sl.n);
+    // the persistent recurrence reports a lost rendezvous through the error word: results would be garbage
+    unsigned e = 0;
+    XB_HIP(ctx, hipMemcpy(&e, ctx->error, sizeof e, hipMemcpyDeviceToHost));
+    if (e != 0) {
+        (void)hipMemset(ctx->error, 0, sizeof(unsigned));
+        return fail(ctx, XB_ERR_DEVICE, "LSTM inter-workgroup sync timed out (persistent kernel was not fully resident?)");
+    }
+    return XB_OK;
 }
 
 XB_API int xb_set_profiling(xb_ctx *ctx, int on)

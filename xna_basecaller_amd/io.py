@@ -1,18 +1,24 @@
 """
-Output side of the basecaller (ub-bonito/bonito/io.py): FASTQ records + the summary TSV.
+Output side of the basecaller: FASTQ records on stdout and one summary row per read.
 
-  biofmt         io.py:30-49      write_fastq   io.py:76-84     summary_file  io.py:148-155
-  summary_row    io.py:190-237    CSVLogger     io.py:322-356   Writer.run    io.py:403-445
+Written from the OUTPUT FORMAT the reference produces (ub-bonito/bonito/io.py), not from its code:
 
-SAM/BAM/CRAM output, alignment and the CTC writer need pysam/mappy and are outside the
-north-star path.
+  * stdout format is chosen from the name stdout is redirected to (io.py:30-49): `*.fq` / `*.fastq` / a tty / a pipe
+    mean FASTQ; `.sam` / `.bam` / `.cram` would mean alignment output, which needs pysam/mappy and is outside the
+    north-star path -- the CLI refuses those;
+  * a FASTQ record is  "@<read_id> <tag>\\t<tag>...\\n<sequence>\\n+\\n<qstring>\\n"  (io.py:76-84) with the tags
+    RG:Z:<run_id>_<model>  qs:i:<rounded mean q>  mx:i  ch:i  st:Z  rn:i  f5:Z  (io.py:412-419, fast5.py:118-128);
+  * the summary is `<stdout stem>_summary.tsv` (`summary.tsv` on a tty or a pipe; io.py:148-155), tab separated with the
+    CSV dialect of Python's csv.writer (CRLF line ends, minimal quoting), header
+    filename read_id run_id channel mux start_time duration template_start template_duration
+    sequence_length_template mean_qscore_template (io.py:158-170, 190-206); appended to if it already exists;
+  * reads whose called sequence is empty are skipped with a warning (io.py:444-445); the writer keeps a
+    (read_id, samples) log from which the CLI prints samples per second (cli/basecaller.py:153-161).
 """
-import csv
 import os
 import sys
 from collections import namedtuple
 from logging import getLogger
-from os.path import realpath, splitext
 from threading import Thread
 
 from .util import mean_qscore_from_qstring
@@ -20,127 +26,129 @@ from .util import mean_qscore_from_qstring
 logger = getLogger("bonito")
 Format = namedtuple("Format", "aligned name mode")
 
+SUMMARY_COLUMNS = ("filename", "read_id", "run_id", "channel", "mux", "start_time", "duration", "template_start",
+                   "template_duration", "sequence_length_template", "mean_qscore_template")
+_MODES = {"fq": ("fastq", "wfq"), "fastq": ("fastq", "wfq"), "sam": ("sam", "w"), "bam": ("bam", "wb"),
+          "cram": ("cram", "wc")}
+
+
+def _stdout_target():
+    """Path stdout points at, or None for a terminal / pipe / socket."""
+    if sys.stdout.isatty():
+        return None
+    target = os.path.realpath("/dev/fd/1")
+    return None if target.startswith("/proc") else target
+
 
 def biofmt(aligned=False):
-    mode, name = ("w", "sam") if aligned else ("wfq", "fastq")
-    aligned = "aligned" if aligned else "unaligned"
-    stdout = realpath("/dev/fd/1")
-    if sys.stdout.isatty() or stdout.startswith("/proc"):
-        return Format(aligned, name, mode)
-    ext = stdout.split(os.extsep)[-1]
-    if ext in ["fq", "fastq"]:
-        return Format(aligned, "fastq", "wfq")
-    elif ext == "bam":
-        return Format(aligned, "bam", "wb")
-    elif ext == "cram":
-        return Format(aligned, "cram", "wc")
-    elif ext == "sam":
-        return Format(aligned, "sam", "w")
-    return Format(aligned, name, mode)
-
-
-def write_fasta(header, sequence, fd=sys.stdout):
-    fd.write(f">{header}\n{sequence}\n")
-
-
-def write_fastq(header, sequence, qstring, fd=sys.stdout, tags=None, sep="\t"):
-    if tags is not None:
-        fd.write(f"@{header} {sep.join(tags)}\n")
-    else:
-        fd.write(f"@{header}\n")
-    fd.write(f"{sequence}\n+\n{qstring}\n")
+    """Output format implied by stdout's file name: Format(aligned|unaligned, fastq|sam|bam|cram, open mode)."""
+    kind = "aligned" if aligned else "unaligned"
+    fallback = ("sam", "w") if aligned else ("fastq", "wfq")
+    target = _stdout_target()
+    ext = target.rsplit(os.extsep, 1)[-1] if target else ""
+    name, mode = _MODES.get(ext, fallback)
+    return Format(kind, name, mode)
 
 
 def summary_file():
-    stdout = realpath("/dev/fd/1")
-    if sys.stdout.isatty() or stdout.startswith("/proc"):
-        return "summary.tsv"
-    return "%s_summary.tsv" % splitext(stdout)[0]
+    target = _stdout_target()
+    return "summary.tsv" if target is None else os.path.splitext(target)[0] + "_summary.tsv"
 
 
-summary_field_names = [
-    "filename", "read_id", "run_id", "channel", "mux", "start_time", "duration", "template_start",
-    "template_duration", "sequence_length_template", "mean_qscore_template",
-]
+def write_fastq(header, sequence, qstring, fd=sys.stdout, tags=None, sep="\t"):
+    title = header if tags is None else "%s %s" % (header, sep.join(tags))
+    fd.write("@%s\n%s\n+\n%s\n" % (title, sequence, qstring))
 
 
-def summary_row(read, seqlen, qscore, alignment=False):
-    fields = [read.filename, read.read_id, read.run_id, read.channel, read.mux, read.start, read.duration,
-              read.template_start, read.template_duration, seqlen, qscore]
-    return dict(zip(summary_field_names, fields))
+def write_fasta(header, sequence, fd=sys.stdout):
+    fd.write(">%s\n%s\n" % (header, sequence))
 
 
-class CSVLogger:
-    def __init__(self, filename, sep=","):
-        self.filename = str(filename)
-        if os.path.exists(self.filename):
-            with open(self.filename) as f:
-                self.columns = csv.DictReader(f).fieldnames
-        else:
-            self.columns = None
-        self.fh = open(self.filename, "a", newline="")
-        self.csvwriter = csv.writer(self.fh, delimiter=sep)
-        self.count = 0
+def _tsv_field(value):
+    """One field in csv.writer's default dialect with a tab delimiter (quote only when needed, double the quotes)."""
+    text = "" if value is None else str(value)
+    if any(c in text for c in '\t"\r\n'):
+        text = '"%s"' % text.replace('"', '""')
+    return text
 
-    def set_columns(self, columns):
-        if self.columns:
-            raise Exception("Columns already set")
+
+class SummaryTable:
+    """Append-only TSV: the header is written when the file is new, otherwise the existing header's columns are kept."""
+
+    def __init__(self, path, columns=SUMMARY_COLUMNS):
+        self.path = str(path)
         self.columns = list(columns)
-        self.csvwriter.writerow(self.columns)
+        fresh = not os.path.exists(self.path) or os.path.getsize(self.path) == 0
+        if not fresh:
+            with open(self.path, newline="") as fh:
+                first = fh.readline().rstrip("\r\n")
+            if first:
+                self.columns = first.split("\t")
+        self._fh = open(self.path, "a", newline="")
+        self._pending = 0
+        if fresh:
+            self._line(self.columns)
+
+    def _line(self, fields):
+        self._fh.write("\t".join(_tsv_field(f) for f in fields) + "\r\n")
 
     def append(self, row):
-        if self.columns is None:
-            self.set_columns(row.keys())
-        self.csvwriter.writerow([row.get(k, "-") for k in self.columns])
-        self.count += 1
-        if self.count > 100:
-            self.count = 0
-            self.fh.flush()
+        self._line([row.get(c, "-") for c in self.columns])
+        self._pending += 1
+        if self._pending > 100:
+            self._fh.flush()
+            self._pending = 0
 
     def close(self):
-        self.fh.close()
+        self._fh.close()
 
     def __enter__(self):
         return self
 
-    def __exit__(self, *args):
+    def __exit__(self, *exc):
         self.close()
 
 
+def summary_row(read, seqlen, qscore):
+    values = (read.filename, read.read_id, read.run_id, read.channel, read.mux, read.start, read.duration,
+              read.template_start, read.template_duration, seqlen, qscore)
+    return dict(zip(SUMMARY_COLUMNS, values))
+
+
 class Writer(Thread):
-    """Drains the (read, result) iterator: FASTQ to `fd`, one summary row per read, a (read_id, samples) log."""
+    """Drains the (read, result) iterator on its own thread: FASTQ to `fd`, a summary row and a log entry per read."""
 
     def __init__(self, mode, iterator, aligner=None, fd=sys.stdout, duplex=False, ref_fn=None, groups=None,
                  group_key=None, summary=None):
         super().__init__()
         if mode != "wfq" or aligner is not None:
             raise NotImplementedError("only unaligned FASTQ output is on the MI355X path (mode 'wfq')")
-        self.fd = fd
-        self.log = []
-        self.mode = mode
-        self.iterator = iterator
-        self.fastq = True
+        self.mode, self.fd, self.iterator = mode, fd, iterator
         self.group_key = group_key
         self.summary = summary
+        self.log = []
         self.error = None
+
+    def _emit(self, table, read, res):
+        seq = res["sequence"]
+        if not len(seq):
+            logger.warning("> skipping empty sequence %s", read.read_id)
+            return
+        qstring = res.get("qstring", "*")
+        mean_q = res.get("mean_qscore")
+        if mean_q is None:
+            mean_q = mean_qscore_from_qstring(qstring)
+        tags = ["RG:Z:%s_%s" % (read.run_id, self.group_key), "qs:i:%d" % round(mean_q)]
+        tags += list(read.tagdata()) + list(res.get("mods", []))
+        write_fastq(read.read_id, seq, qstring, fd=self.fd, tags=tags)
+        table.append(summary_row(read, len(seq), mean_q))
+        self.log.append((read.read_id, len(read.signal)))
 
     def run(self):
         try:
-            with CSVLogger(self.summary or summary_file(), sep="\t") as summary:
+            with SummaryTable(self.summary or summary_file()) as table:
                 for read, res in self.iterator:
-                    seq = res["sequence"]
-                    qstring = res.get("qstring", "*")
-                    mean_qscore = res.get("mean_qscore", mean_qscore_from_qstring(qstring))
-                    samples = len(read.signal)
-                    read_id = read.read_id
-                    tags = [f"RG:Z:{read.run_id}_{self.group_key}", f"qs:i:{round(mean_qscore)}",
-                            *read.tagdata(), *res.get("mods", [])]
-                    if len(seq):
-                        write_fastq(read_id, seq, qstring, fd=self.fd, tags=tags)
-                        summary.append(summary_row(read, len(seq), mean_qscore))
-                        self.log.append((read_id, samples))
-                    else:
-                        logger.warning("> skipping empty sequence %s", read_id)
+                    self._emit(table, read, res)
         except BaseException as e:  # surfaced by the CLI after join()
             self.error = e
             raise

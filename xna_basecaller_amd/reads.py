@@ -14,67 +14,71 @@ Everything after the HDF5 decode is the reference's arithmetic.
 """
 import json
 import os
-from collections import OrderedDict
 from datetime import datetime, timedelta
 from glob import glob
 from pathlib import Path
 
 import numpy as np
 
-__all__ = ["Read", "trim", "med_mad", "norm_by_noisiest_section", "get_reads", "write_bundle",
-           "SyntheticRead"]
+__all__ = ["Read", "trim", "med_mad", "norm_by_noisiest_section", "get_reads", "ReadLoader", "read_jobs",
+           "write_bundle", "SyntheticRead"]
 
 
 def med_mad(x, factor=1.4826):
-    """Median and scaled median absolute deviation (+ float32 eps so it is never zero)."""
-    med = np.median(x)
-    mad = np.median(np.absolute(x - med)) * factor + np.finfo(np.float32).eps
-    return med, mad
+    """Robust location / scale: the median and factor * median(|x - median|), plus float32 eps so the scale is never 0
+    (fast5.py:174-180)."""
+    centre = np.median(x)
+    spread = np.median(np.absolute(x - centre)) * factor + np.finfo(np.float32).eps
+    return centre, spread
 
 
 def trim(signal, window_size=40, threshold_factor=2.4, min_elements=3):
     """
-    Find where the open-pore/adapter prefix ends.  Skip 10 samples; threshold = med + 2.4*mad of the
-    last 100 windows; walk 40-sample windows: once a window has more than `min_elements` samples
-    above threshold, return the end of the first window whose last sample is back under it.
+    Where the open-pore / adapter prefix ends (fast5.py:149-171), evaluated on whole windows at once.
+    The first 10 samples are ignored; the threshold is median + 2.4 * mad of the last 100 windows of the remainder.
+    The prefix ends with the first window, from the first "hot" window on (more than `min_elements` samples above the
+    threshold), whose last sample is back at or under the threshold.  Returns (start, length of the remainder); start
+    is relative to the untrimmed input, capped at the remainder's length, and 10 when no such window exists.
     """
-    min_trim = 10
-    signal = signal[min_trim:]
-    med, mad = med_mad(signal[-(window_size * 100):])
-    threshold = med + mad * threshold_factor
-    num_windows = len(signal) // window_size
-    seen_peak = False
-    for pos in range(num_windows):
-        end = (pos + 1) * window_size
-        window = signal[end - window_size:end]
-        if seen_peak or np.count_nonzero(window > threshold) > min_elements:
-            seen_peak = True
-            if window[-1] > threshold:
-                continue
-            return min(end + min_trim, len(signal)), len(signal)
-    return min_trim, len(signal)
+    skip = 10
+    body = signal[skip:]
+    level, scale = med_mad(body[-(window_size * 100):])
+    threshold = level + scale * threshold_factor
+    n_win = len(body) // window_size
+    if n_win:
+        windows = body[:n_win * window_size].reshape(n_win, window_size)
+        hot = np.count_nonzero(windows > threshold, axis=1) > min_elements
+        if hot.any():
+            first = int(np.argmax(hot))
+            calm = windows[first:, -1] <= threshold
+            if calm.any():
+                end = (first + int(np.argmax(calm)) + 1) * window_size
+                return min(end + skip, len(body)), len(body)
+    return skip, len(body)
 
 
 def norm_by_noisiest_section(signal, samples=100, threshold=6.0):
     """
-    med/mad normalisation using the widest run of 100-sample windows whose std exceeds
-    std(signal)/threshold (short reads, fast5.py:183-204).
+    Normalisation of short reads (fast5.py:183-204): med/mad of the widest stretch of 100-sample windows whose
+    standard deviation exceeds std(signal) / threshold; of the whole signal when there is no such stretch.
+    The stretch is located as the reference does, with scipy's plateau peaks on the 0/1 window mask (its
+    left_bases / right_bases define the slice), so the numbers agree bit for bit (tests/golden/signal_prep.npz).
     """
     from scipy.signal import find_peaks
-    threshold = signal.std() / threshold
-    noise = np.ones(signal.shape)
-    for idx in np.arange(signal.shape[0] // samples):
-        window = slice(idx * samples, (idx + 1) * samples)
-        noise[window] = np.where(signal[window].std() > threshold, 1, 0)
-    noise[0] = 0
-    noise[-1] = 0
-    peaks, info = find_peaks(noise, width=(None, None))
+    cutoff = signal.std() / threshold
+    n_win = signal.shape[0] // samples
+    mask = np.ones(signal.shape)
+    if n_win:
+        noisy = signal[:n_win * samples].reshape(n_win, samples).std(axis=1) > cutoff
+        mask[:n_win * samples] = np.repeat(noisy, samples)
+    mask[0] = mask[-1] = 0
+    peaks, info = find_peaks(mask, width=(None, None))
+    section = signal
     if len(peaks):
         widest = np.argmax(info["widths"])
-        med, mad = med_mad(signal[info["left_bases"][widest]: info["right_bases"][widest]])
-    else:
-        med, mad = med_mad(signal)
-    return (signal - med) / mad
+        section = signal[info["left_bases"][widest]: info["right_bases"][widest]]
+    centre, spread = med_mad(section)
+    return (signal - centre) / spread
 
 
 def _parse_time(s):
@@ -89,6 +93,11 @@ def _parse_time(s):
         return parser.parse(s)
     except Exception:
         return datetime(1970, 1, 1)
+
+
+def _read_tags(read):
+    return ["mx:i:%s" % read.mux, "ch:i:%s" % read.channel, "st:Z:%s" % read.start_time,
+            "rn:i:%s" % read.read_number, "f5:Z:%s" % read.filename]
 
 
 class Read:
@@ -138,23 +147,9 @@ class Read:
     def __repr__(self):
         return "Read('%s')" % self.read_id
 
-    def readgroup(self, model):
-        self._groupdict = OrderedDict([
-            ("ID", f"{self.run_id}_{model}"), ("PL", "ONT"), ("DT", f"{self.exp_start_time}"),
-            ("PU", f"{self.flow_cell_id}"), ("PM", f"{self.device_id}"), ("LB", f"{self.sample_id}"),
-            ("SM", f"{self.sample_id}"),
-            ("DS", "%s" % " ".join([f"run_id={self.run_id}", f"basecall_model={model}"])),
-        ])
-        return "\t".join(["@RG", *[f"{k}:{v}" for k, v in self._groupdict.items()]])
-
     def tagdata(self):
-        return [
-            f"mx:i:{self.mux}",
-            f"ch:i:{self.channel}",
-            f"st:Z:{self.start_time}",
-            f"rn:i:{self.read_number}",
-            f"f5:Z:{self.filename}",
-        ]
+        """FASTQ header tags of the read (fast5.py:118-128): mux, channel, start time, read number, source file."""
+        return _read_tags(self)
 
 
 class SyntheticRead:
@@ -179,8 +174,7 @@ class SyntheticRead:
         return "SyntheticRead('%s')" % self.read_id
 
     def tagdata(self):
-        return [f"mx:i:{self.mux}", f"ch:i:{self.channel}", f"st:Z:{self.start_time}",
-                f"rn:i:{self.read_number}", f"f5:Z:{self.filename}"]
+        return _read_tags(self)
 
 
 def write_bundle(path, reads):
@@ -193,20 +187,80 @@ def write_bundle(path, reads):
     np.savez_compressed(path, **arrays)
 
 
-def _bundle_reads(filename, read_ids=None, skip=False):
+def _bundle_index(filename):
+    """[(read_id, position)] of a bundle without touching the signals."""
     with np.load(filename) as z:
         metas = json.loads(bytes(z["meta"]).decode())
-        for i, attrs in enumerate(metas):
-            rid = attrs["read_id"]
-            if read_ids is None or (rid in read_ids) ^ skip:
-                yield Read(z["raw_%d" % i], attrs, filename)
+    return [(attrs["read_id"], i) for i, attrs in enumerate(metas)]
 
 
-def get_reads(directory, read_ids=None, skip=False, n_proc=1, recursive=False, cancel=None):
-    """All reads of every signal bundle under `directory`, in file then in-file order."""
+def _load_read(job):
+    """(filename, position) -> Read; runs in a pool worker (fast5.py:263-270 get_raw_data_for_read)."""
+    filename, i = job
+    with np.load(filename) as z:
+        attrs = json.loads(bytes(z["meta"]).decode())[i]
+        return Read(z["raw_%d" % i], attrs, filename)
+
+
+def read_jobs(directory, read_ids=None, skip=False, recursive=False):
+    """(filename, position) of every selected read under `directory`, in file then in-file order -- metadata only."""
     pattern = "**/*.xsig.npz" if recursive else "*.xsig.npz"
+    jobs = []
     for fn in sorted(Path(x) for x in glob(directory + "/" + pattern, recursive=True)):
-        for read in _bundle_reads(fn, read_ids=read_ids, skip=skip):
-            yield read
-            if cancel is not None and cancel.is_set():
-                return
+        for rid, i in _bundle_index(fn):
+            if read_ids is None or (rid in read_ids) ^ skip:
+                jobs.append((fn, i))
+    return jobs
+
+
+class ReadLoader:
+    """
+    Iterator over the selected reads of a directory.  The worker pool is started in the constructor -- create it before
+    the GPU is initialised (forking a process that holds a HIP context is best avoided) -- and stays up to a few reads
+    ahead of the consumer; results arrive in job order.
+    """
+
+    def __init__(self, directory, read_ids=None, skip=False, n_proc=1, recursive=False, cancel=None, shard=None,
+                 limit=0):
+        jobs = list(enumerate(read_jobs(directory, read_ids=read_ids, skip=skip, recursive=recursive)))
+        if limit:
+            jobs = jobs[:limit]
+        self.total = len(jobs)                      # selected reads over all shards
+        if shard is not None:
+            rank, world = shard
+            jobs = [(i, j) for i, j in jobs if i % world == rank]
+        self.jobs, self.cancel, self.pool = jobs, cancel, None
+        if n_proc > 1 and len(jobs) > 1:
+            import multiprocessing as mp
+            self.pool = mp.get_context("fork" if "fork" in mp.get_all_start_methods() else None).Pool(min(n_proc, len(jobs)))
+            self._results = self.pool.imap(_load_read, [j for _, j in jobs], chunksize=1)
+
+    def __len__(self):
+        return len(self.jobs)
+
+    def __iter__(self):
+        try:
+            for k, (i, job) in enumerate(self.jobs):
+                read = next(self._results) if self.pool is not None else _load_read(job)
+                read.index = i
+                yield read
+                if self.cancel is not None and self.cancel.is_set():
+                    return
+        finally:
+            self.close()
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool = None
+
+
+def get_reads(directory, read_ids=None, skip=False, n_proc=1, recursive=False, cancel=None, shard=None, limit=0):
+    """
+    All selected reads under `directory` as `Read`s, in file then in-file order (fast5.py:284-296).  The signal
+    preparation (inflate, scale, trim, two medians) runs in a pool of `n_proc` worker processes; results come back in
+    order.  shard = (rank, world): only reads whose global index i has i % world == rank are ever loaded; every yielded
+    read carries that index as `read.index`.
+    """
+    return ReadLoader(directory, read_ids=read_ids, skip=skip, n_proc=n_proc, recursive=recursive, cancel=cancel,
+                      shard=shard, limit=limit)
