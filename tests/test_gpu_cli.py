@@ -94,3 +94,35 @@ def test_cli_basecaller_end_to_end(tmp_path):
         if seq != ref:
             mism += sum(a != b for a, b in zip(seq, ref)) + abs(len(seq) - len(ref))
     assert mism <= total // 500, (mism, total)       # encoder differences of ~1e-5 may flip a near-tie
+
+
+def test_cli_reads_fast5_like_bundles(tmp_path):
+    """The same reads as multi-read fast5 files (HDF5 + VBZ, parsed by hdf5_lite) and as signal bundles give the same
+    FASTQ records (apart from the f5:Z: source-file tag)."""
+    from h5write import write_multi_fast5
+    labels = list("NACGTXY")
+    model_dir = str(tmp_path / "xna_test@v1")
+    _make_model_dir(model_dir, 64, labels, seed=21)
+    rng = np.random.default_rng(12)
+    recs = []
+    for i in range(8):
+        length = int(rng.integers(3000, 12000))
+        base = rng.normal(90.0, 12.0, length)
+        base[: int(rng.integers(300, 900))] = 140.0
+        recs.append((np.round(base * 8.0).astype(np.int16),
+                     dict(read_id="aaaa-%02d" % i, range=1443.03, digitisation=8192.0, offset=10, sampling_rate=4000.0,
+                          run_id="runX", channel_number=str(100 + i), start_mux=1 + i % 4, read_number=i,
+                          start_time=4000 * i, duration=length, exp_start_time="2021-06-01T10:00:00Z")))
+    (tmp_path / "f5").mkdir()
+    (tmp_path / "npz").mkdir()
+    write_multi_fast5(str(tmp_path / "f5" / "batch_0.fast5"), recs, vbz=True)
+    xreads.write_bundle(str(tmp_path / "npz" / "batch_0.xsig.npz"), recs)
+    outs = {}
+    for kind in ("f5", "npz"):
+        out = tmp_path / ("calls_%s.fastq" % kind)
+        with open(out, "w") as fh:
+            r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, str(tmp_path / kind),
+                                "--batch", "6"], cwd=ROOT, stdout=fh, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()
+        outs[kind] = out.read_text().replace("f5:Z:batch_0.fast5", "f5:Z:X").replace("f5:Z:batch_0.xsig.npz", "f5:Z:X")
+    assert outs["f5"] == outs["npz"] and outs["f5"].count("\n") == 32

@@ -205,3 +205,80 @@ def test_reverse_complement_matches_reference():
             got = sd.reverse_complement(x)
             assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"]
             assert np.array_equal(got.astype(np.int64), z["nb%d_sl%d" % (nb, sl)])
+
+
+def _fast5_records(n, seed=5):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        length = int(rng.integers(2500, 15000))
+        base = rng.normal(90.0, 12.0, length)
+        base[: int(rng.integers(300, 900))] = 140.0
+        raw = np.round(base * 8.0).astype(np.int16)
+        if i == 1:
+            raw[100:110] = [-32768, 32767, -1, 0, 1, 255, 256, -256, -255, 12345]     # delta / zig-zag extremes
+        recs.append((raw, dict(read_id="0a1b2c3d-%04d" % i, range=1443.03, digitisation=8192.0, offset=10,
+                               sampling_rate=4000.0, run_id="runF5", channel_number=str(7 + i), start_mux=1 + i % 4,
+                               read_number=100 + i, start_time=4000 * i, duration=length,
+                               exp_start_time="2021-06-01T10:00:00Z", sample_id="s1", flow_cell_id="FAK1",
+                               device_id="MN1")))
+    return recs
+
+
+@pytest.mark.parametrize("vbz,vlen", [(True, False), (False, True)])
+def test_fast5_reader_equals_bundle_path(tmp_path, vbz, vlen):
+    """get_reads(dir of fast5) yields Reads equal to the bundle path: the file is a multi-read fast5
+    written by the test itself in the classic HDF5 layout (tests/h5write.py), VBZ-compressed or plain chunks, fixed or
+    variable-length string attributes."""
+    from h5write import write_multi_fast5
+    recs = _fast5_records(6)
+    d5, dn = tmp_path / "f5", tmp_path / "npz"
+    d5.mkdir()
+    dn.mkdir()
+    write_multi_fast5(str(d5 / "batch_0.fast5"), recs[:4], vbz=vbz, vlen_strings=vlen)
+    write_multi_fast5(str(d5 / "batch_1.fast5"), recs[4:], vbz=vbz, vlen_strings=vlen, chunk=1000)
+    xreads.write_bundle(str(dn / "all.xsig.npz"), recs)
+    a = sorted(xreads.get_reads(str(d5)), key=lambda r: r.read_id)
+    b = sorted(xreads.get_reads(str(dn)), key=lambda r: r.read_id)
+    assert [r.read_id for r in a] == [r.read_id for r in b] and len(a) == 6
+    for x, y in zip(a, b):
+        assert np.array_equal(x.signal, y.signal) and x.signal.dtype == np.float32
+        for k in ("run_id", "channel", "mux", "read_number", "start", "duration", "template_start",
+                  "template_duration", "start_time", "sample_id", "flow_cell_id", "device_id", "offset", "scaling"):
+            assert getattr(x, k) == getattr(y, k), k
+        assert x.filename.endswith(".fast5") and x.tagdata()[:4] == y.tagdata()[:4]
+    # read-id filter, pool and sharding go through the same job list
+    ids = {recs[1][1]["read_id"], recs[5][1]["read_id"]}
+    assert sorted(r.read_id for r in xreads.get_reads(str(d5), read_ids=ids, n_proc=2)) == sorted(ids)
+    assert [r.index for r in xreads.get_reads(str(d5), shard=(1, 2))] == [1, 3, 5]
+
+
+def test_hdf5_lite_basics(tmp_path):
+    from h5write import H5Writer
+    from xna_basecaller_amd import hdf5_lite
+    w = H5Writer()
+    w._vlen_patches = []
+    x = np.arange(10, dtype=np.int32)
+    y = (np.arange(7000) % 300 - 150).astype(np.int16)
+    dx = w.dataset(x, attrs={"unit": "pA", "gain": np.float32(2.5)})
+    dy = w.dataset(y, chunks=2048, vbz=True)
+    dz = w.dataset(np.linspace(0, 1, 5))
+    g, _, _ = w.group({"x": dx, "y": dy}, attrs={"note": "vlen:variable length text", "n": np.int64(-3)})
+    root = w.group({"grp": g, "z": dz}, attrs={"file_version": "2.2"})
+    w.finish(str(tmp_path / "t.h5"), root)
+    with hdf5_lite.File(str(tmp_path / "t.h5")) as f:
+        assert sorted(f.keys()) == ["grp", "z"] and f.attrs["file_version"] == "2.2"
+        assert "grp/x" in f and "nope" not in f
+        assert np.array_equal(f["grp/x"][:], x) and f["grp/x"].shape == (10,)
+        assert f["grp/x"].attrs["unit"] == "pA" and f["grp/x"].attrs["gain"] == 2.5
+        assert np.array_equal(f["grp"]["y"][:], y) and f["grp/y"].dtype == np.int16
+        assert np.allclose(f["z"][:], np.linspace(0, 1, 5))
+        assert f["grp"].attrs["note"] == "variable length text" and f["grp"].attrs["n"] == -3
+    with pytest.raises(hdf5_lite.Hdf5Error):
+        (tmp_path / "bad.h5").write_bytes(b"not hdf5" * 100)
+        hdf5_lite.File(str(tmp_path / "bad.h5"))
+    # VBZ round trip on awkward data (wrap-around differences, odd lengths)
+    for n in (0, 1, 7, 8, 9, 1000):
+        v = np.random.default_rng(n).integers(-32768, 32768, n).astype(np.int16)
+        enc = hdf5_lite.vbz_encode_int16(v, level=1)
+        assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(enc, [0, 2, 1, 1]), dtype="<i2"), v)

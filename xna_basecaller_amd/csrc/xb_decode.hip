@@ -296,7 +296,8 @@ __device__ __forceinline__ void load_seg(const float *p, float (&r)[CNT])
     (void)o;
 }
 
-constexpr int RDEPTH = 8;     // register-ring depth (time steps in flight)
+constexpr int RDEPTH = 8;     // register-ring depth (time steps in flight), sweep 2 (a whole staged row per step)
+constexpr int RDEPTH13 = 16;  // sweeps 1 and 3: a lane's ring entry is only E (or E/2) floats
 constexpr int LRING = 128;    // arg-max partial ring (steps); finalised 64 at a time
 
 // coalesced row staging for sweep 2: NR 16-byte groups per thread, loaded RDEPTH steps ahead, written to LDS per step
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     constexpr int NRS = VW == 4 ? (E + 3) / 4 : E;     // staging pieces per thread (BS * NRS * VW >= S * E >= cin)
     constexpr int cpad = BS * NRS * VW;                // staged row (floats)
     const int lim_m = VW == 4 ? (cin + 3) & ~3 : cin;  // vector loads may touch the row's padding columns
-    const int Tpad = (T + RDEPTH - 1) / RDEPTH * RDEPTH;
+    const int Tpad = (T + RDEPTH13 - 1) / RDEPTH13 * RDEPTH13;   // multiple of both ring depths
 
     float *sM = reinterpret_cast<float *>(smem_raw);             // [2][cpad]  staged score row (sweep 2)
     float *sQ = sM + 2 * cpad;                                    // [2][cpad]  Q rows being assembled (sweep 2)
@@ -426,18 +427,18 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         // first score column this lane loads, and the register index of local edge r: mv[r + moff]
         const int col0 = HB ? (ph == 0 ? j * E : j * E + E - EPER) : (ph == 0 ? j * NB : j * NB + H - 1);
         if (tid < S) { sA[tid] = 0.0f; alpha[tid] = 0.0f; }        // alpha_0 = 0 in any order
-        float ring[RDEPTH][CPL];
+        float ring[RDEPTH13][CPL];
 #pragma unroll
-        for (int d = 0; d < RDEPTH; ++d) load_seg<CPL>(sc + (size_t)(d < T ? d : T - 1) * tstride + col0, ring[d]);
+        for (int d = 0; d < RDEPTH13; ++d) load_seg<CPL>(sc + (size_t)(d < T ? d : T - 1) * tstride + col0, ring[d]);
         float aown = 0.0f;
-        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
+        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH13) {
 #pragma unroll
-          for (int d = 0; d < RDEPTH; ++d) {
+          for (int d = 0; d < RDEPTH13; ++d) {
             const int t = t0 + d;                                // >= T in the padding iterations
             float mv[CPL];
 #pragma unroll
             for (int r = 0; r < CPL; ++r) mv[r] = ring[d][r];
-            load_seg<CPL>(sc + (size_t)(t + RDEPTH < T ? t + RDEPTH : T - 1) * tstride + col0, ring[d]);
+            load_seg<CPL>(sc + (size_t)(t + RDEPTH13 < T ? t + RDEPTH13 : T - 1) * tstride + col0, ring[d]);
             lds_barrier();
             if (t < T) {                                         // block-uniform
                 const float *a0 = sA + (t & 1) * S;
@@ -631,10 +632,10 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         const int col0 = ph == 0 ? j * E : j * E + E - EPER;      // this lane's first Q column (never past the row)
         const int k0 = LPS == 1 ? 0 : ph * H;
         if (tid < S) sX[tid] = 0.0f;
-        float qring[RDEPTH][EPER];
-        float mring[RDEPTH];
+        float qring[RDEPTH13][EPER];
+        float mring[RDEPTH13];
 #pragma unroll
-        for (int d = 0; d < RDEPTH; ++d) {
+        for (int d = 0; d < RDEPTH13; ++d) {
             const int t = d < T ? d : T - 1;
             load_seg<EPER>(qrow + (size_t)t * qstride + col0, qring[d]);
             mring[d] = bmax[(size_t)(t + 1) * sstride + j];
@@ -657,19 +658,19 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             }
         };
         float aown = 0.0f;
-        static_assert(RDEPTH % 4 == 0, "the arg-max reductions are batched four steps at a time");
-        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH) {
-          float bestv[RDEPTH];
-          int bestc[RDEPTH];
+        static_assert(RDEPTH13 % 4 == 0 && RDEPTH13 % RDEPTH == 0, "the arg-max reductions are batched four steps at a time");
+        for (int t0 = 0; t0 < Tpad; t0 += RDEPTH13) {
+          float bestv[RDEPTH13];
+          int bestc[RDEPTH13];
 #pragma unroll
-          for (int d = 0; d < RDEPTH; ++d) {
+          for (int d = 0; d < RDEPTH13; ++d) {
             const int t = t0 + d;                                // >= T in the padding iterations
             float qv[EPER];
 #pragma unroll
             for (int r = 0; r < EPER; ++r) qv[r] = qring[d][r];
             const float m1j = mring[d];
             {
-                const int tn = t + RDEPTH < T ? t + RDEPTH : T - 1;
+                const int tn = t + RDEPTH13 < T ? t + RDEPTH13 : T - 1;
                 load_seg<EPER>(qrow + (size_t)tn * qstride + col0, qring[d]);
                 mring[d] = bmax[(size_t)(tn + 1) * sstride + j];
             }

@@ -7,10 +7,10 @@ Read objects and signal preparation (ub-bonito/bonito/fast5.py).
   norm_by_noisiest_section                                    fast5.py:183-204
   get_reads                                                   fast5.py:284-296
 
-fast5 is HDF5 + the VBZ filter; neither libhdf5/h5py nor ont_fast5_api exists in this image,
-so reads come from a pre-extracted signal bundle (`*.xsig.npz`, written by `write_bundle`):
-raw int16 DACs plus the attributes fast5.py reads (channel_id, tracking_id, Raw attrs).
-Everything after the HDF5 decode is the reference's arithmetic.
+Two containers are read: `*.fast5` (HDF5 + ONT's VBZ filter; neither libhdf5/h5py nor ont_fast5_api exists in this
+image, so the files are parsed by the package's own minimal reader, hdf5_lite.py) and a pre-extracted signal bundle
+(`*.xsig.npz`, written by `write_bundle`): raw int16 DACs plus the attributes fast5.py reads (channel_id,
+tracking_id, Raw attrs).  Everything after the container decode is the reference's arithmetic.
 """
 import json
 import os
@@ -194,22 +194,84 @@ def _bundle_index(filename):
     return [(attrs["read_id"], i) for i, attrs in enumerate(metas)]
 
 
+# ---- fast5 (HDF5) -------------------------------------------------------------------------------------------------
+def _fast5_layout(f):
+    """'multi' (/read_<id>/Raw/Signal, ont_fast5_api multi-read files) or 'single' (/Raw/Reads/Read_<n>/Signal)."""
+    keys = f.keys()
+    if any(k.startswith("read_") for k in keys):
+        return "multi"
+    if "Raw" in keys and "UniqueGlobalKey" in keys:
+        return "single"
+    raise ValueError("%s: neither a multi-read nor a single-read fast5 file" % f.path)
+
+
+def _fast5_index(filename):
+    """[(read_id, group name)] of a fast5 file, in the file's own (name sorted) order."""
+    from . import hdf5_lite
+    with hdf5_lite.File(filename) as f:
+        if _fast5_layout(f) == "multi":
+            return [(k[len("read_"):], k) for k in f.keys() if k.startswith("read_")]
+        reads = f["Raw/Reads"]
+        return [(str(reads[k].attrs.get("read_id", k)), "Raw/Reads/" + k) for k in reads.keys()]
+
+
+def _text(v, default=""):
+    if v is None:
+        return default
+    if isinstance(v, (bytes, np.bytes_)):
+        return v.decode("ascii", "replace")
+    return str(v)
+
+
+def _fast5_read(filename, group):
+    """One read of a fast5 file -> Read.  The attribute set is the one fast5.py:24-76 consumes."""
+    from . import hdf5_lite
+    with hdf5_lite.File(filename) as f:
+        if group.startswith("Raw/Reads/"):                   # single-read layout
+            raw_grp = f[group]
+            chan, track = f["UniqueGlobalKey/channel_id"].attrs, f["UniqueGlobalKey/tracking_id"].attrs
+            run_id = track.get("run_id", "")
+        else:
+            node = f[group]
+            raw_grp = node["Raw"]
+            chan, track = node["channel_id"].attrs, node["tracking_id"].attrs
+            run_id = node.attrs.get("run_id", track.get("run_id", ""))
+        ra = raw_grp.attrs
+        attrs = {
+            "read_id": _text(ra.get("read_id", group.split("_", 1)[-1])),
+            "run_id": _text(run_id), "sample_id": _text(track.get("sample_id"), "None"),
+            "exp_start_time": _text(track.get("exp_start_time"), "1970-01-01T00:00:00"),
+            "flow_cell_id": _text(track.get("flow_cell_id")), "device_id": _text(track.get("device_id"), "None"),
+            "range": float(chan["range"]), "digitisation": float(chan["digitisation"]), "offset": int(chan["offset"]),
+            "sampling_rate": float(chan["sampling_rate"]), "channel_number": _text(chan.get("channel_number"), "0"),
+            "start_mux": int(ra.get("start_mux", 0)), "read_number": int(ra.get("read_number", 0)),
+            "start_time": int(ra.get("start_time", 0)),
+        }
+        raw = raw_grp["Signal"][:]
+        attrs["duration"] = int(ra.get("duration", len(raw)))
+        return Read(raw, attrs, filename)
+
+
 def _load_read(job):
-    """(filename, position) -> Read; runs in a pool worker (fast5.py:263-270 get_raw_data_for_read)."""
-    filename, i = job
+    """(filename, key) -> Read; runs in a pool worker (fast5.py:263-270 get_raw_data_for_read)."""
+    filename, key = job
+    if str(filename).endswith(".fast5"):
+        return _fast5_read(filename, key)
     with np.load(filename) as z:
-        attrs = json.loads(bytes(z["meta"]).decode())[i]
-        return Read(z["raw_%d" % i], attrs, filename)
+        attrs = json.loads(bytes(z["meta"]).decode())[key]
+        return Read(z["raw_%d" % key], attrs, filename)
 
 
 def read_jobs(directory, read_ids=None, skip=False, recursive=False):
-    """(filename, position) of every selected read under `directory`, in file then in-file order -- metadata only."""
-    pattern = "**/*.xsig.npz" if recursive else "*.xsig.npz"
+    """(filename, key) of every selected read under `directory` -- `*.fast5` files (multi- or single-read HDF5, parsed
+    by hdf5_lite) and `*.xsig.npz` signal bundles -- in file then in-file order; metadata only."""
     jobs = []
-    for fn in sorted(Path(x) for x in glob(directory + "/" + pattern, recursive=True)):
-        for rid, i in _bundle_index(fn):
-            if read_ids is None or (rid in read_ids) ^ skip:
-                jobs.append((fn, i))
+    for ext, index in ((".fast5", _fast5_index), (".xsig.npz", _bundle_index)):
+        pattern = ("**/*" if recursive else "*") + ext
+        for fn in sorted(Path(x) for x in glob(directory + "/" + pattern, recursive=True)):
+            for rid, key in index(fn):
+                if read_ids is None or (rid in read_ids) ^ skip:
+                    jobs.append((fn, key))
     return jobs
 
 
