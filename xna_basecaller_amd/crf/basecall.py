@@ -77,29 +77,36 @@ def _scores_dict(sequence):
     }
 
 
-def compute_scores_pipelined(model, batches, reverse=False):
+def compute_sequences_pipelined(model, batches, reverse=False):
     """
-    compute_scores over a stream of (key, batch) with TWO batches in flight on the device: batch k+1 is submitted
-    (pinned staging, H2D on a copy stream, fused kernels, D2H) before batch k's result is waited for, so the GPU
-    never idles while the host unpacks results.  Results come out in input order, one batch late.
+    The device stage of `basecall`: (key, batch) stream -> (key, sequence (n,T) int8 left-packed ASCII) with TWO batches
+    in flight on the device: batch k+1 is submitted (pinned staging, H2D on a copy stream, fused kernels, D2H) before
+    batch k's result is waited for, so the GPU never idles while the host unpacks results.  Results come out in input
+    order, one batch late.  (compute_scores is the same operator, synchronous, with the reference's full result dict.)
     """
     if reverse or not model.encoder[-1].expand_blanks:
         for key, batch in batches:                       # decode of host-side reverse-complemented scores: synchronous
-            yield key, compute_scores(model, batch, reverse=reverse)
+            yield key, compute_scores(model, batch, reverse=reverse)["sequence"]
         return
     pending, slot = None, 0
     for key, batch in batches:
         shape = np.asarray(batch).shape
         if pending is not None and not model.context_is_current(shape[-1], shape[0]):
-            yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])     # drain before the context is rebuilt
+            yield pending[0], model.collect_chunks(pending[1])[0]        # drain before the context is rebuilt
             pending = None
         handle = model.submit_chunks(slot, batch)
         slot ^= 1
         if pending is not None:
-            yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])
+            yield pending[0], model.collect_chunks(pending[1])[0]
         pending = (key, handle)
     if pending is not None:
-        yield pending[0], _scores_dict(model.collect_chunks(pending[1])[0])
+        yield pending[0], model.collect_chunks(pending[1])[0]
+
+
+def compute_scores_pipelined(model, batches, reverse=False):
+    """compute_scores over a stream of (key, batch), two batches in flight; yields the reference's result dicts."""
+    for key, sequence in compute_sequences_pipelined(model, batches, reverse=reverse):
+        yield key, _scores_dict(sequence)
 
 
 def to_str(x, encoding="ascii"):
@@ -120,6 +127,18 @@ def apply_stride_to_moves(model, attrs):
     }
 
 
+def _called(model, sequence):
+    """
+    The per-read result of crf/basecall.py:85-93 from the stitched left-packed row alone.  The Viterbi branch's quality
+    string and moves are placeholders that mirror the sequence (crf/basecall.py:60-76: 'O' wherever a base was written,
+    no moves), so stitching them separately and then dropping their padding gives exactly 'O' * len(sequence) and an
+    all-False signal-move vector of one entry per stitched slot and stride.
+    """
+    seq = to_str(sequence)
+    return {"qstring": "O" * len(seq), "sequence": seq, "sig_move": np.zeros(np.asarray(sequence).size * model.stride, dtype=bool),
+            "mean_qscore": 40.0 if seq else 0.0}           # = mean_qscore_from_qstring('O' * n), util.py:124-131
+
+
 def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False):
     """Basecall `reads` (objects with .signal); yields (read, {'sequence','qstring','sig_move'}) in input order."""
     chunks = thread_iter(
@@ -127,12 +146,12 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
         for read in reads
     )
     batches = thread_iter(batchify(chunks, batchsize=batchsize))
-    scores = thread_iter(compute_scores_pipelined(model, batches, reverse=reverse))
+    sequences = thread_iter(compute_sequences_pipelined(model, batches, reverse=reverse))
     results = thread_iter(
-        (read, stitch_results(sc, end - start, chunksize, overlap, model.stride, reverse))
-        for ((read, start, end), sc) in unbatchify(scores)
+        (read, stitch(seq, chunksize, overlap, end - start, model.stride, reverse=reverse))
+        for ((read, start, end), seq) in unbatchify(sequences)
     )
     return thread_iter(
-        (read, apply_stride_to_moves(model, attrs))
-        for read, attrs in results
+        (read, _called(model, stitched))
+        for read, stitched in results
     )
