@@ -242,3 +242,24 @@ def test_encoder_edge_shapes(features, nb, L, N):
     pick = sorted({0, N // 2, N - 1})
     ref = oracle.encode(x[pick], sd, features, nb, 3, expand_blanks=False)
     assert np.abs(outs[1][:, pick] - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("N", [384, 128, 640])
+def test_encoder_batches_that_are_multiples_of_128(N):
+    """The reference's shipped batch size is 384 (config.toml:26-29): a multiple of 128 but not of the GEMM's 256-row tile.
+    Those batches take the unchecked member-major gin epilogue per WAVE (128 rows); every chunk must still agree with
+    the per-step launch mode bit for bit and with the oracle."""
+    F, nb, L = 64, 6, 720 * 5 // 6           # T = 120
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=7)
+    x = np.random.default_rng(N).standard_normal((N, L)).astype(np.float32)
+    out = []
+    for mode in (2, 1):
+        ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        out.append(ctx.encode(x, expand_blanks=False))
+        ctx.close()
+    assert np.array_equal(out[0], out[1])
+    picks = sorted({0, 1, 127, min(128, N - 1), N // 2, max(N - 129, 0), N - 128, N - 1})
+    ref = oracle.encode(x[picks], sd, F, nb, 3, expand_blanks=False)
+    assert np.abs(ref - out[0][:, picks]).max() < 2e-4
