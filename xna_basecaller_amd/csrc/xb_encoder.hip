@@ -348,7 +348,10 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     if (!gemm_tile_origin(p, m0, n0)) return;
     const int nk = p.K / GBK;
     // (Starting the first round of workgroups in four phases spread over a tile time, so that one CU's epilogue burst would
-    // overlap its neighbours' main loops, was measured: 49.5 vs 49.4 ms per five GEMMs -- the CUs do not run in lock-step.)
+    // overlap its neighbours' main loops, was measured: 49.5 vs 49.4 ms per five GEMMs -- the CUs do not run in lock-step.
+    // Exchanging the MFMA operand roles so that a lane holds four consecutive gin columns of one row -- 32 dwordx4 stores
+    // per lane instead of 128 single-dword ones -- was measured too: 54.0 ms (plain stores) / 77.9 ms (non-temporal): each
+    // 128-byte line is then written in four 32-byte pieces; whole lines per half-wave, as below, are what the memory side wants.)
 
     // ---- staging source: wave-uniform tile bases (SGPRs) + 32-bit lane byte offsets.  Lane i of wave w moves slot i of rows
     //      16w..16w+15 of a half-tile part: row 16w + (i >> 2), LDS cell (i & 3) <- source cell (i & 3) ^ ((row >> 2) & 3).
