@@ -11,7 +11,11 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no exceptions across the ABI.
  *   - every function returns XB_OK (0) or a negative xb_status; xb_last_error(ctx) gives text.
- *   - one xb_ctx per GPU; it owns its HIP streams (a main stream plus two low-priority side streams: the next
+ *   - one xb_ctx per GPU, and the GPU to itself: the persistent LSTM kernel keeps up to 192 workgroups (one per CU, all
+ *     of the CU's registers) resident and exchanging data for a whole layer; a second tenant on the same device (another
+ *     process, a CU mask) can keep part of them from becoming resident, in which case the waiting workgroups give up
+ *     after a bounded spin and the next xb_synchronize / xb_collect_chunks reports XB_ERR_DEVICE.
+ *   - the ctx owns its HIP streams (a main stream plus two low-priority side streams: the next
  *     layer's input GEMM runs beside the current layer's recurrence, the CRF decode of one batch beside the encoder
  *     of the next) and every device buffer it allocates.  A ctx is
  *     used by one thread at a time (the reference calls compute_scores from ONE pipeline

@@ -106,3 +106,37 @@ def test_pipelined_device_calls_match_blocking_calls():
             assert np.array_equal(l.cpu().numpy(), elen)
             assert np.array_equal(s.cpu().numpy(), eseq)
     ctx.close()
+
+
+def test_submit_collect_pipeline_matches_blocking_calls():
+    """xb_submit_chunks / xb_collect_chunks: two batches in flight through the pinned staging slots give what the
+    blocking entry point gives, in order; slot misuse is an XB_ERR_STATE, not undefined behaviour."""
+    from xna_basecaller_amd import _lib
+    F, nb, L, N = 64, 6, 1500, 40
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=5)
+    ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
+    ctx.load_state_dict(sd)
+    alphabet = "NACGTXY"
+    rng = np.random.default_rng(8)
+    batches = [rng.standard_normal((n, L)).astype(np.float32) for n in (40, 17, 40, 1, 33, 40)]
+    expect = [ctx.basecall_chunks(x, alphabet) for x in batches]
+    got, pending, slot = [], None, 0
+    for x in batches:
+        n = ctx.submit_chunks(slot, x, alphabet)
+        x[:] = 0                                  # the caller's buffer is free again as soon as submit returns
+        if pending is not None:
+            got.append(ctx.collect_chunks(*pending))
+        pending, slot = (slot, n), slot ^ 1
+    got.append(ctx.collect_chunks(*pending))
+    for (es, el), (gs, gl) in zip(expect, got):
+        assert np.array_equal(el, gl) and np.array_equal(es, gs)
+    with pytest.raises(_lib.XbError) as e:
+        ctx.collect_chunks(0, 1)                  # nothing in flight
+    assert e.value.code == -4
+    ctx.submit_chunks(1, batches[1][:3] + 1.0, alphabet)
+    with pytest.raises(_lib.XbError) as e:
+        ctx.submit_chunks(1, batches[1][:3], alphabet)     # slot still in flight
+    assert e.value.code == -4
+    ctx.collect_chunks(1, 3)
+    ctx.close()

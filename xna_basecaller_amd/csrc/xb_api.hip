@@ -83,6 +83,7 @@ struct xb_ctx {
     unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
     unsigned *error = nullptr;
     int lstm_mode = 0;
+    int lstm_resident = -1;      // workgroups of the persistent kernel admitted per CU (occupancy query, lazily)
 
     bool profiling = false;
     std::vector<StageEvent> events;
@@ -324,7 +325,10 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     // groups per persistent launch: every workgroup must be resident at once, and workgroups are dealt to the 8 XCDs
     // strictly round-robin (block b -> XCD b % 8), i.e. groups g, g + 8, .. share ONE XCD's CUs: F = 768 (24 members per
     // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
-    const int gmax = 8 * ((ctx->cu_count / 8) / members);
+    // ... and the occupancy calculator has to admit at least one such workgroup per CU (queried once per context); a
+    // context that cannot keep the persistent kernel resident falls back to one launch per time step
+    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx));
+    const int gmax = ctx->lstm_resident >= 1 ? 8 * ((ctx->cu_count / 8) / members) : 0;
     if (mode == 0) mode = gmax >= 1 ? 2 : 1;
     if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
     XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));

@@ -1069,6 +1069,44 @@ bool lstm_supported_features(int F)
     default: return false;
     }
 }
+template <int KS>
+static int lstm_occupancy_ks(int nsplit)
+{
+    constexpr int F = KS * 16;
+    constexpr int KP = F < 128 ? F : 128;
+    const int nparts = nsplit == 1 ? 1 : 2;
+    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
+                       sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16 + 16 + 80;
+    int nb = 0;
+    hipError_t e;
+    if (nsplit == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 3>, 256, lds);
+    } else if (nsplit == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 2>, 256, lds);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 1>, 256, lds);
+    }
+    return e == hipSuccess ? nb : 0;
+}
+
+int lstm_resident_per_cu(int F, int nsplit)
+{
+    switch (F / 16) {
+    case 2: return lstm_occupancy_ks<2>(nsplit);
+    case 4: return lstm_occupancy_ks<4>(nsplit);
+    case 6: return lstm_occupancy_ks<6>(nsplit);
+    case 8: return lstm_occupancy_ks<8>(nsplit);
+    case 16: return lstm_occupancy_ks<16>(nsplit);
+    case 24: return lstm_occupancy_ks<24>(nsplit);
+    case 32: return lstm_occupancy_ks<32>(nsplit);
+    case 48: return lstm_occupancy_ks<48>(nsplit);
+    default: return 0;
+    }
+}
+
 int lstm_members(int F) { return F / LG_UNITS; }
 int lstm_group_chunks() { return LG_BN; }
 

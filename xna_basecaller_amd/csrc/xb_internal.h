@@ -101,6 +101,9 @@ struct LstmParams {
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
+// workgroups of the persistent kernel the occupancy calculator admits per CU for feature size F (0: the kernel cannot be
+// resident at all, e.g. LDS or registers taken by another tenant's limits); the persistent mode needs >= 1
+int lstm_resident_per_cu(int F, int nsplit);
 int lstm_members(int F);
 int lstm_group_chunks();
 bool lstm_supported_features(int F);
