@@ -282,3 +282,30 @@ def test_hdf5_lite_basics(tmp_path):
         v = np.random.default_rng(n).integers(-32768, 32768, n).astype(np.int16)
         enc = hdf5_lite.vbz_encode_int16(v, level=1)
         assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(enc, [0, 2, 1, 1]), dtype="<i2"), v)
+
+
+def test_new_style_typed_encoder_config():
+    """crf/model.py:231-232: a config whose [encoder] has a 'type' goes through from_dict; the typed form of the
+    rnn_encoder stack builds the same model (same state-dict keys and shapes), anything else is rejected."""
+    from xna_basecaller_amd.crf.model import Model
+    F = 96
+    conv = lambda i, o, w, s, p: dict(type="convolution", insize=i, size=o, bias=True, winlen=w, stride=s, padding=p, activation="swish")
+    subs = [conv(1, 4, 5, 1, 2), conv(4, 16, 5, 1, 2), conv(16, F, 19, 5, 9), dict(type="permute", dims=[2, 0, 1])]
+    subs += [dict(type="lstm", size=F, insize=F, bias=True, reverse=(i % 2 == 0)) for i in range(5)]
+    subs += [dict(type="linearcrfencoder", insize=F, n_base=6, state_len=3, bias=True, scale=5.0, activation="tanh", blank_score=2.0)]
+    cfg = make_config(F)
+    old = Model(cfg)
+    cfg2 = make_config(F)
+    cfg2["encoder"] = dict(type="serial", sublayers=subs)
+    new = Model(cfg2)
+    assert [(k, tuple(v.shape)) for k, v in new.state_dict().items()] == [(k, tuple(v.shape)) for k, v in old.state_dict().items()]
+    assert new.stride == 5 and new._features == F and new.encoder[-1].blank_score == 2.0 and new.encoder[-1].expand_blanks
+    # a TOML round trip of the typed form (array of tables)
+    text = toml_lite.dumps(cfg2)
+    assert toml_lite.loads(text)["encoder"]["sublayers"][8]["reverse"] is True
+    bad = [dict(d) for d in subs]
+    bad[5]["reverse"] = True                                   # wrong direction pattern
+    cfg3 = make_config(F)
+    cfg3["encoder"] = dict(type="serial", sublayers=bad)
+    with pytest.raises(NotImplementedError):
+        Model(cfg3)

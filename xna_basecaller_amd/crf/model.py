@@ -113,6 +113,47 @@ def rnn_encoder(n_base, state_len, insize=1, stride=5, winlen=19, activation="sw
     )
 
 
+def encoder_from_dict(spec, n_base, state_len):
+    """
+    New-style typed encoder config (crf/model.py:231-232, nn.py:244-259 `from_dict`): {'type': 'serial', 'sublayers':
+    [{'type': 'convolution', ...} x3, {'type': 'permute', 'dims': [2, 0, 1]}, {'type': 'lstm', ...} x5,
+    {'type': 'linearcrfencoder', ...}]} -- what `to_dict` writes for the rnn_encoder architecture.  Any other layer
+    list is outside the hot path (the kernels implement exactly this stack) and is rejected with the reason.
+    Returns (encoder, geometry) with geometry = dict(features, winlen, stride, scale, blank_score).
+    """
+    def bad(why):
+        raise NotImplementedError("typed encoder config is not the rnn_encoder stack the MI355X path implements: " + why)
+
+    if spec.get("type") != "serial" or not isinstance(spec.get("sublayers"), list):
+        bad("top level must be {'type': 'serial', 'sublayers': [...]}")
+    subs = [dict(d) for d in spec["sublayers"] if d.get("type") != "dropout"]      # inference: dropout is the identity
+    kinds = [d.get("type") for d in subs]
+    if kinds != ["convolution"] * 3 + ["permute"] + ["lstm"] * 5 + ["linearcrfencoder"]:
+        bad("layer types %s" % kinds)
+    c1, c2, c3 = subs[0:3]
+    feats = int(c3["size"])
+    want = [dict(insize=1, size=4, winlen=5, stride=1, padding=2), dict(insize=4, size=16, winlen=5, stride=1, padding=2),
+            dict(insize=16, size=feats, winlen=int(c3["winlen"]), stride=int(c3["stride"]), padding=int(c3["winlen"]) // 2)]
+    for i, (c, w) in enumerate(zip((c1, c2, c3), want)):
+        got = {k: int(c.get(k, {"stride": 1, "padding": 0}.get(k, -1))) for k in w}
+        if got != w or c.get("activation") != "swish" or not c.get("bias", True):
+            bad("convolution %d is %s" % (i, c))
+    if list(subs[3].get("dims", [])) != [2, 0, 1]:
+        bad("permute dims %s" % subs[3].get("dims"))
+    for i, l in enumerate(subs[4:9]):
+        if int(l["size"]) != feats or int(l["insize"]) != feats or not l.get("bias", True) or bool(l.get("reverse", False)) != (i % 2 == 0):
+            bad("lstm %d is %s (expected size %d, directions reverse,forward,reverse,forward,reverse)" % (i, l, feats))
+    lin = subs[9]
+    if int(lin["insize"]) != feats or int(lin["n_base"]) != n_base or int(lin["state_len"]) != state_len:
+        bad("linearcrfencoder %s does not match labels / state_len" % lin)
+    enc = rnn_encoder(n_base, state_len, insize=1, stride=int(c3["stride"]), winlen=int(c3["winlen"]), activation="swish",
+                      features=feats, scale=lin.get("scale"), blank_score=lin.get("blank_score"),
+                      expand_blanks=lin.get("expand_blanks", True))
+    if lin.get("activation") != "tanh" or not lin.get("bias", True):
+        bad("linearcrfencoder %s" % lin)
+    return enc, dict(features=feats, winlen=int(c3["winlen"]), stride=int(c3["stride"]))
+
+
 def _device_index(device):
     if isinstance(device, int):
         return device
@@ -128,11 +169,12 @@ class Model(torch.nn.Module):
     def __init__(self, config):
         super().__init__()
         self.seqdist = CTC_CRF(state_len=config["global_norm"]["state_len"], alphabet=config["labels"]["labels"])
-        if "type" in config["encoder"]:
-            raise NotImplementedError("new-style (typed) encoder configs are not supported")
-        enc = {k: v for k, v in config["encoder"].items()}
-        self.encoder = rnn_encoder(self.seqdist.n_base, self.seqdist.state_len,
-                                   insize=config["input"]["features"], **enc)
+        if "type" in config["encoder"]:          # new-style (typed) config, crf/model.py:231-232
+            self.encoder, enc = encoder_from_dict(config["encoder"], self.seqdist.n_base, self.seqdist.state_len)
+        else:                                      # old-style: keyword arguments of rnn_encoder
+            enc = {k: v for k, v in config["encoder"].items()}
+            self.encoder = rnn_encoder(self.seqdist.n_base, self.seqdist.state_len,
+                                       insize=config["input"]["features"], **enc)
         self.stride = enc.get("stride", 5)
         self.alphabet = self.seqdist.alphabet
         self.config = config

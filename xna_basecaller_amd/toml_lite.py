@@ -117,12 +117,18 @@ def loads(text):
         if not line:
             continue
         if line.startswith("[") and "=" not in line.split("]")[0]:
-            if line.startswith("[["):
-                raise ValueError("arrays of tables are not supported")
-            name = line.strip("[] \t")
+            is_array = line.startswith("[[")              # [[a.b]]: append a new table to the array a.b
+            parts = [p.strip().strip('"') for p in line.strip("[] \t").split(".")]
             table = root
-            for part in name.split("."):
-                table = table.setdefault(part.strip().strip('"'), {})
+            for i, part in enumerate(parts):
+                last = i == len(parts) - 1
+                if last and is_array:
+                    arr = table.setdefault(part, [])
+                    arr.append({})
+                    table = arr[-1]
+                else:
+                    nxt = table.setdefault(part, {})
+                    table = nxt[-1] if isinstance(nxt, list) else nxt       # [a.b.c] below [[a.b]]: its latest element
             continue
         key, sep, val = line.partition("=")
         if not sep:
@@ -156,10 +162,12 @@ def _fmt(v):
 
 
 def dumps(d, _prefix=""):
-    lines, tables = [], []
+    lines, tables, arrays = [], [], []
     for k, v in d.items():
         if isinstance(v, dict):
             tables.append((k, v))
+        elif isinstance(v, (list, tuple)) and v and all(isinstance(x, dict) for x in v):
+            arrays.append((k, v))                         # array of tables: [[prefix.k]] per element
         else:
             lines.append("%s = %s" % (k, _fmt(v)))
     out = "\n".join(lines)
@@ -167,4 +175,8 @@ def dumps(d, _prefix=""):
         name = _prefix + k
         body = dumps(v, name + ".")
         out += ("\n\n" if out else "") + "[%s]\n%s" % (name, body)
+    for k, v in arrays:
+        name = _prefix + k
+        for item in v:
+            out += ("\n\n" if out else "") + "[[%s]]\n%s" % (name, dumps(item, name + "."))
     return out + ("\n" if not _prefix and not out.endswith("\n") else "")
