@@ -828,11 +828,11 @@ int decode_lanes_per_state(int S, int N)
         const int v = atoi(e);
         if ((v == 1 || v == 2) && v * S <= 1024) return v;
     }
-    (void)N;
-    // two lanes per state halve the per-lane chain of exps (a step is bound by its dependency chain) at the price of a
-    // workgroup twice as wide; measured on MI355X, N = 512, T = 2000: S = 125: 3.84 (2 lanes) vs 4.87 ms (1 lane);
-    // S = 216: 8.57 (448 threads) vs 6.54 ms (256 threads)
-    return 2 * S <= 256 ? 2 : 1;
+    // Two lanes per state halve the per-lane chain of exps at the price of a workgroup twice as wide (the pair's per-state
+    // work is done by both lanes).  That pays while the batch leaves a CU only ~2 workgroups; with more chunks per CU the
+    // narrower workgroup wins.  Measured on MI355X, T = 2000 (ms, 2 lanes vs 1 lane): S = 125: N = 512 3.78 vs 4.77,
+    // N = 1024 7.16 vs 6.22, N = 2048 12.99 vs 12.20; S = 216: N = 512 8.72 vs 6.28, N = 1024 17.41 vs 12.22.
+    return (2 * S <= 256 && N <= 768) ? 2 : 1;
 }
 
 // Host-side launch.  Shapes are validated here so the kernel's indexing assumptions hold:
