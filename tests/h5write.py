@@ -19,9 +19,11 @@ def _pad8(b):
 
 
 class H5Writer:
-    def __init__(self):
+    def __init__(self, fanout=0):
         self.buf = bytearray(96)                       # room for the superblock (version 0: 96 bytes with 8-byte sizes)
         self.gheap = []                                # objects of the single global heap collection
+        self.fanout = fanout                           # > 0: at most `fanout` entries per B-tree / symbol-table node,
+                                                       # i.e. multi-level trees like libhdf5 writes for large objects
 
     # ---- raw allocation --------------------------------------------------------------------------------------
     def alloc(self, data, align=8):
@@ -106,12 +108,22 @@ class H5Writer:
                 block[:part.size] = part
                 raw = vbz_encode_int16(block, level=1) if vbz else block.tobytes()
                 entries.append((o, len(raw), self.alloc(raw)))
-            # one leaf B-tree node (type 1); keys: chunk size, filter mask, offsets (rank + 1 values)
-            node = b"TREE" + struct.pack("<BBHQQ", 1, 0, len(entries), UNDEF, UNDEF)
-            for o, size, addr in entries:
-                node += struct.pack("<IIQQ", size, 0, o, 0) + struct.pack("<Q", addr)
-            node += struct.pack("<IIQQ", 0, 0, a.shape[0] + ((-a.shape[0]) % chunks), 0)      # final key
-            bt = self.alloc(node)
+            # B-tree v1 nodes of type 1; keys: chunk size, filter mask, offsets (rank + 1 values); children of a leaf are
+            # the chunks, children of an internal node are nodes one level down (key = first chunk below)
+            end_key = struct.pack("<IIQQ", 0, 0, a.shape[0] + ((-a.shape[0]) % chunks), 0)
+            level, fan = 0, (self.fanout or len(entries) or 1)
+            while True:
+                nodes = []
+                for g0 in range(0, max(len(entries), 1), fan):
+                    grp = entries[g0:g0 + fan]
+                    node = b"TREE" + struct.pack("<BBHQQ", 1, level, len(grp), UNDEF, UNDEF)
+                    for o, size, addr in grp:
+                        node += struct.pack("<IIQQ", size, 0, o, 0) + struct.pack("<Q", addr)
+                    nodes.append((grp[0][0] if grp else 0, 0, self.alloc(node + end_key)))
+                if len(nodes) == 1:
+                    bt = nodes[0][2]
+                    break
+                entries, level = nodes, level + 1
             msgs.append((0x0008, struct.pack("<BBBQII", 3, 2, 2, bt, chunks, a.dtype.itemsize)))
             if vbz:
                 name = _pad8(b"vbz\0")
@@ -131,13 +143,28 @@ class H5Writer:
             heap += _pad8(n.encode() + b"\0")
         heap_data = self.alloc(bytes(heap))
         heap_hdr = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), UNDEF, heap_data))
-        snod = b"SNOD" + struct.pack("<BBH", 1, 0, len(names))
-        for n in names:
-            snod += struct.pack("<QQII16x", offs[n], children[n], 0, 0)
-        snod_addr = self.alloc(snod)
-        last = offs[names[-1]] if names else 0
-        tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, last)
-        bt = self.alloc(tree)
+        # symbol-table nodes of at most `fan` entries under B-tree v1 nodes of type 0 (keys = heap offsets of names)
+        fan = self.fanout or max(len(names), 1)
+        kids = []                                                        # (last name offset, address)
+        for g0 in range(0, max(len(names), 1), fan):
+            grp = names[g0:g0 + fan]
+            snod = b"SNOD" + struct.pack("<BBH", 1, 0, len(grp))
+            for n in grp:
+                snod += struct.pack("<QQII16x", offs[n], children[n], 0, 0)
+            kids.append((offs[grp[-1]] if grp else 0, self.alloc(snod)))
+        level = 0
+        while True:
+            nodes = []
+            for g0 in range(0, len(kids), fan):
+                grp = kids[g0:g0 + fan]
+                tree = b"TREE" + struct.pack("<BBHQQ", 0, level, len(grp), UNDEF, UNDEF) + struct.pack("<Q", 0)
+                for last, addr in grp:
+                    tree += struct.pack("<QQ", addr, last)
+                nodes.append((grp[-1][0], self.alloc(tree)))
+            if len(nodes) == 1:
+                bt = nodes[0][1]
+                break
+            kids, level = nodes, level + 1
         msgs = [(0x0011, struct.pack("<QQ", bt, heap_hdr))]
         for k, v in (attrs or {}).items():
             msgs.append(self.attr_msg(k, v))
@@ -176,14 +203,14 @@ class H5Writer:
             fh.write(bytes(self.buf))
 
 
-def write_multi_fast5(path, reads, vbz=True, chunk=4096, vlen_strings=False):
+def write_multi_fast5(path, reads, vbz=True, chunk=4096, vlen_strings=False, fanout=0):
     """
     reads: [(raw int16 array, attrs)] with the attrs of reads.write_bundle (read_id, range, digitisation, offset,
     sampling_rate, run_id, channel_number, start_mux, read_number, start_time, duration, exp_start_time, ...).
     Layout (ont_fast5_api multi-read files): /read_<id>/Raw{Signal + attrs}, /read_<id>/channel_id{attrs},
     /read_<id>/tracking_id{attrs}; the root carries file_type / file_version.
     """
-    w = H5Writer()
+    w = H5Writer(fanout=fanout)
     w._vlen_patches = []
     top = {}
     s = (lambda v: "vlen:" + v) if vlen_strings else (lambda v: v)

@@ -140,3 +140,28 @@ def test_abi_error_paths():
     with pytest.raises(_lib.XbError):
         ctx.decode(random_scores(17, 2, 6), "NACGTXY")              # T above the context's T
     ctx.close()
+
+
+def test_decode_random_shapes(monkeypatch):
+    """Seeded sweep over small random shapes (T, N, alphabet, blank layout, lanes per state, score scale): every
+    combination must be bit-exact -- ring depths (8 / 16), the 64-step label finalisation and the padded tail iterations
+    all have their own boundaries."""
+    rng = np.random.default_rng(20261004)
+    ctxs = {}
+    for case in range(40):
+        nb = int(rng.integers(4, 7))
+        T = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 63, 64, 65, 127, 128, 129, 191, 200, int(rng.integers(3, 260))]))
+        N = int(rng.integers(1, 8))
+        with_blank = bool(rng.integers(0, 2))
+        lps = int(rng.integers(1, 3))
+        monkeypatch.setenv("XB_DECODE_LPS", str(lps))
+        ctx = ctxs.get(nb)
+        if ctx is None:
+            ctx = ctxs[nb] = _ctx(nb, 260, 8)
+        sc = random_scores(T, N, nb, seed=1000 + case, with_blank=with_blank)
+        if case % 5 == 0:
+            body = sc.reshape(T, N, nb ** 3, -1)
+            body[..., (1 if with_blank else 0):] *= float(rng.choice([0.25, 3.0, 8.0]))     # peaky / flat / far outside tanh range
+        _check(ctx, sc, nb, "NACGTXY"[:nb + 1], blank=None if with_blank else 2.0)
+    for ctx in ctxs.values():
+        ctx.close()

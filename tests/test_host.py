@@ -236,7 +236,8 @@ def test_fast5_reader_equals_bundle_path(tmp_path, vbz, vlen):
     d5.mkdir()
     dn.mkdir()
     write_multi_fast5(str(d5 / "batch_0.fast5"), recs[:4], vbz=vbz, vlen_strings=vlen)
-    write_multi_fast5(str(d5 / "batch_1.fast5"), recs[4:], vbz=vbz, vlen_strings=vlen, chunk=1000)
+    # second file: small chunks and a B-tree fan-out of 3, i.e. multi-level chunk and group B-trees
+    write_multi_fast5(str(d5 / "batch_1.fast5"), recs[4:], vbz=vbz, vlen_strings=vlen, chunk=1000, fanout=3)
     xreads.write_bundle(str(dn / "all.xsig.npz"), recs)
     a = sorted(xreads.get_reads(str(d5)), key=lambda r: r.read_id)
     b = sorted(xreads.get_reads(str(dn)), key=lambda r: r.read_id)
@@ -256,14 +257,15 @@ def test_fast5_reader_equals_bundle_path(tmp_path, vbz, vlen):
 def test_hdf5_lite_basics(tmp_path):
     from h5write import H5Writer
     from xna_basecaller_amd import hdf5_lite
-    w = H5Writer()
+    w = H5Writer(fanout=2)                                  # two entries per node: three-level trees below
     w._vlen_patches = []
     x = np.arange(10, dtype=np.int32)
     y = (np.arange(7000) % 300 - 150).astype(np.int16)
     dx = w.dataset(x, attrs={"unit": "pA", "gain": np.float32(2.5)})
     dy = w.dataset(y, chunks=2048, vbz=True)
     dz = w.dataset(np.linspace(0, 1, 5))
-    g, _, _ = w.group({"x": dx, "y": dy}, attrs={"note": "vlen:variable length text", "n": np.int64(-3)})
+    many = {"d%02d" % i: w.dataset(np.full(3, i, dtype=np.int16)) for i in range(11)}
+    g, _, _ = w.group(dict(many, x=dx, y=dy), attrs={"note": "vlen:variable length text", "n": np.int64(-3)})
     root = w.group({"grp": g, "z": dz}, attrs={"file_version": "2.2"})
     w.finish(str(tmp_path / "t.h5"), root)
     with hdf5_lite.File(str(tmp_path / "t.h5")) as f:
@@ -274,6 +276,8 @@ def test_hdf5_lite_basics(tmp_path):
         assert np.array_equal(f["grp"]["y"][:], y) and f["grp/y"].dtype == np.int16
         assert np.allclose(f["z"][:], np.linspace(0, 1, 5))
         assert f["grp"].attrs["note"] == "variable length text" and f["grp"].attrs["n"] == -3
+        assert sorted(f["grp"].keys()) == sorted(["d%02d" % i for i in range(11)] + ["x", "y"])
+        assert all(f["grp/d%02d" % i][:].tolist() == [i] * 3 for i in range(11))
     with pytest.raises(hdf5_lite.Hdf5Error):
         (tmp_path / "bad.h5").write_bytes(b"not hdf5" * 100)
         hdf5_lite.File(str(tmp_path / "bad.h5"))
