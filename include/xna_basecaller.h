@@ -60,7 +60,9 @@ typedef enum xb_status {
 typedef enum xb_precision {
     XB_PREC_F16X3 = 0,        /* split-fp16 MFMA, 3 products, fp32 accumulate: |score err| ~3e-6 */
     XB_PREC_F16 = 1,          /* single fp16 MFMA, fp32 accumulate (the reference's model.half()): ~1e-3 */
-    XB_PREC_F16F8 = 2         /* fp16 main product + both correction products on the block-scaled FP8 MFMA: ~4e-5 */
+    XB_PREC_F16F8 = 2,        /* fp16 main product + both correction products on the block-scaled FP8 MFMA: ~4e-5 */
+    XB_PREC_F16F8_IN1 = 3     /* as F16F8, but the LSTM input projections (45 % of the FLOPs, no feedback through time) keep
+                                 only the fp16 main product: |score err| ~6e-4 max / 1e-4 rms, 1.19x the throughput */
 } xb_precision;
 
 /*

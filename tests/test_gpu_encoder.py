@@ -263,3 +263,22 @@ def test_encoder_batches_that_are_multiples_of_128(N):
     picks = sorted({0, 1, 127, min(128, N - 1), N // 2, max(N - 129, 0), N - 128, N - 1})
     ref = oracle.encode(x[picks], sd, F, nb, 3, expand_blanks=False)
     assert np.abs(ref - out[0][:, picks]).max() < 2e-4
+
+
+def test_encoder_f16f8_in1_mode_within_north_star_tolerance():
+    """XB_PREC_F16F8_IN1: the LSTM input projections keep only the fp16 main product (they have no feedback through time),
+    recurrence / conv / linear stay f16f8.  Still inside the 1e-3 north-star tolerance, and the launch modes agree bitwise."""
+    F, nb, L, N = 768, 6, 2500, 4
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=25)
+    x = np.random.default_rng(3).standard_normal((N, L)).astype(np.float32)
+    ref = oracle.encode(x, sd, F, nb, 3, expand_blanks=False)
+    out = []
+    for mode in (2, 1):
+        ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8_IN1, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        out.append(ctx.encode(x, expand_blanks=False))
+        ctx.close()
+    assert np.array_equal(out[0], out[1])
+    err = np.abs(out[0] - ref)
+    assert err.max() < TOL and np.sqrt((err ** 2).mean()) < 2e-4, (err.max(), np.sqrt((err ** 2).mean()))

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("XNA_LIBXNACALL", os.path.join(_HERE, "libxnacall.so")
 _lib = None
 
 XB_STAGE_NAMES = ("conv", "lstm_in", "lstm_rec", "linear", "decode")
-XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8 = 0, 1, 2
+XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8, XB_PREC_F16F8_IN1 = 0, 1, 2, 3
 
 EXPORTS = [
     "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",

@@ -184,8 +184,10 @@ class Model(torch.nn.Module):
         self._ctx = None
         self._ctx_key = None
         # f16f8 (default): fp16 product + FP8 block-scaled correction products, |score error| ~4e-5; f16x3: three fp16
-        # products, ~3e-6; f16: one product, ~1e-3 (what the reference's model.half() computes)
-        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8}[
+        # products, ~3e-6; f16: one product, ~1e-3..2e-3 (what the reference's model.half() computes); f16f8i: f16f8 with
+        # single-product LSTM input projections, ~6e-4 max, 1.19x faster
+        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8,
+                          "f16f8i": _lib.XB_PREC_F16F8_IN1}[
             os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "f16f8"))]
 
     # ---- torch.nn.Module surface used by load_model -------------------------------------

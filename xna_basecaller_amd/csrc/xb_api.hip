@@ -266,7 +266,8 @@ int check_device_error(xb_ctx *ctx)
 // ---- encoder orchestration --------------------------------------------------------------
 int precision_nsplit(const xb_ctx *ctx)
 {
-    return ctx->cfg.precision == XB_PREC_F16 ? 1 : (ctx->cfg.precision == XB_PREC_F16F8 ? 2 : 3);
+    const int pr = ctx->cfg.precision;
+    return pr == XB_PREC_F16 ? 1 : ((pr == XB_PREC_F16F8 || pr == XB_PREC_F16F8_IN1) ? 2 : 3);
 }
 
 // the GEMM that consumes a layer's output rows of time steps [ta, tb): the input projection of LSTM layer `layer`
@@ -290,6 +291,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     if (ng.layer < 5) {
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
+        if (ctx->cfg.precision == XB_PREC_F16F8_IN1) g.nsplit = 1;               // main product only (the q8 images stay unused)
         g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
         g.gin_n = n;                                                           // member-major gin (xb_internal.h)
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, st));
@@ -518,7 +520,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (cfg->winlen < 1 || cfg->winlen > 31 || cfg->winlen % 2 == 0 || cfg->stride < 1 || cfg->stride > 8)
         return fail(nullptr, XB_ERR_INVALID, "winlen %d / stride %d unsupported", cfg->winlen, cfg->stride);
     if (cfg->chunk_len < cfg->stride || cfg->max_batch < 1) return fail(nullptr, XB_ERR_INVALID, "bad chunk_len/max_batch");
-    if (cfg->precision != XB_PREC_F16X3 && cfg->precision != XB_PREC_F16 && cfg->precision != XB_PREC_F16F8) return fail(nullptr, XB_ERR_INVALID, "bad precision");
+    if (cfg->precision < XB_PREC_F16X3 || cfg->precision > XB_PREC_F16F8_IN1) return fail(nullptr, XB_ERR_INVALID, "bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, XB_ERR_NO_GPU, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(nullptr, XB_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
@@ -666,7 +668,7 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
     if ((rc = upload(ctx, &ctx->b2, *need("encoder.1.conv.bias")))) return rc;
     if ((rc = upload(ctx, &ctx->b3, *need("encoder.2.conv.bias")))) return rc;
     std::vector<half_t> hi, lo;
-    const bool q8 = ctx->cfg.precision == XB_PREC_F16F8;
+    const bool q8 = ctx->cfg.precision == XB_PREC_F16F8 || ctx->cfg.precision == XB_PREC_F16F8_IN1;
     split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo, q8 ? &ctx->w3_exp : nullptr);
     if ((rc = upload(ctx, &ctx->w3_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->w3_lo, lo))) return rc;
