@@ -313,3 +313,53 @@ def test_new_style_typed_encoder_config():
     cfg3["encoder"] = dict(type="serial", sublayers=bad)
     with pytest.raises(NotImplementedError):
         Model(cfg3)
+
+
+def test_load_model_precedence_and_checkpoint_choice(tmp_path):
+    """util.load_model (util.py:261-366): newest weights_N.tar unless one is named, flag > [basecaller] table >
+    4000/500/64 (overlap 0 is a value, chunksize 0 is 'unset'), skip_top leaves encoder.9 at its initial values,
+    and a checkpoint that does not fit fails loudly.  No GPU: the device context is created lazily."""
+    import torch
+    from xna_basecaller_amd.crf.model import Model
+    cfg = make_config(32)
+    cfg["basecaller"] = {"chunksize": 3600, "batchsize": 384}
+    d = str(tmp_path / "m")
+    os.makedirs(d)
+    open(os.path.join(d, "config.toml"), "w").write(toml_lite.dumps(cfg))
+    ref = Model(make_config(32))
+    g = torch.Generator().manual_seed(5)
+    new = {k: torch.randn(v.shape, generator=g) for k, v in ref.state_dict().items()}
+    torch.save({k: torch.zeros_like(v) for k, v in new.items()}, os.path.join(d, "weights_2.tar"))
+    torch.save({"module." + k: v for k, v in new.items()}, os.path.join(d, "weights_10.tar"))   # 10 > 2 numerically
+    with pytest.raises(FileNotFoundError):
+        util.load_model(str(tmp_path), "cpu")
+
+    m = util.load_model(d, "cuda:0")
+    assert all(torch.equal(v, new[k]) for k, v in m.state_dict().items())
+    assert m.config["basecaller"] == {"chunksize": 3600, "batchsize": 384, "overlap": 500, "quantize": False}
+    assert m.config["encoder"]["drop_rate"] == 0 and m.config["encoder"]["drop_rate_bottom"] == 0
+    m = util.load_model(d, "cuda:0", weights=2, chunksize=0, overlap=0, batchsize=16, quantize=None)
+    assert all(float(v.abs().max()) == 0 for v in m.state_dict().values())
+    assert m.config["basecaller"] == {"chunksize": 3600, "batchsize": 16, "overlap": 0, "quantize": None}
+
+    torch.save(new, os.path.join(d, "weights_9.tar"))      # skip_top filters by the model's key names (no prefix)
+    m = util.load_model(d, "cuda:0", weights=9, skip_top=True, use_koi=True)
+    init = Model(make_config(32)).state_dict()
+    for k, v in m.state_dict().items():
+        if k.startswith("encoder.9"):
+            assert not torch.equal(v, new[k]) and v.shape == init[k].shape
+        else:
+            assert torch.equal(v, new[k])
+
+    wide = Model(make_config(64)).state_dict()
+    torch.save(wide, os.path.join(d, "weights_11.tar"))
+    with pytest.raises((AssertionError, RuntimeError)):
+        util.load_model(d, "cuda:0")
+
+
+def test_column_to_set(tmp_path):
+    f = tmp_path / "ids.tsv"
+    f.write_text("read_id\tx\nr1\t5\nr2 6\n\tr3\t7\n")
+    assert util.column_to_set(str(f), skip_header=True) == {"r1", "r2", "r3"}
+    assert util.column_to_set(str(f), idx=1) == {"x", "5", "6", "7"}
+    assert util.column_to_set(str(tmp_path / "absent")) is None and util.column_to_set(None) is None

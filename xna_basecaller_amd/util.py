@@ -13,7 +13,6 @@ import os
 import re
 import sys
 from collections import OrderedDict
-from glob import glob
 from importlib import import_module
 from itertools import groupby
 from operator import itemgetter
@@ -57,12 +56,15 @@ def mean_qscore_from_qstring(qstring):
 
 
 def column_to_set(filename, idx=0, skip_header=False):
-    """util.py:140-149"""
-    if filename and os.path.isfile(filename):
-        with open(filename, "r") as tsv:
-            if skip_header:
-                next(tsv)
-            return {line.strip().split()[idx] for line in tsv.readlines()}
+    """
+    The set of whitespace-separated field `idx` over the lines of `filename` (read-id lists);
+    None when there is no such file.  Same contract as util.py:140-149.
+    """
+    if not filename or not os.path.isfile(filename):
+        return None
+    with open(filename, "r") as fh:
+        lines = fh.read().splitlines()
+    return {ln.split()[idx] for ln in lines[1 if skip_header else 0:]}
 
 
 # ---------------------------------------------------------------------------------------
@@ -257,54 +259,73 @@ def match_names(state_dict, model, skip_layers=()):
     return OrderedDict((k, remap[k]) for k in state_dict.keys() if k not in skip_layers)
 
 
+def _checkpoint_path(dirname, weights):
+    """weights_<N>.tar for the requested N, or for the largest N present."""
+    if not weights:
+        numbers = [int(m.group(1)) for m in
+                   (re.search(r"weights_([0-9]+)\.tar$", f) for f in os.listdir(dirname)) if m]
+        if not numbers:
+            raise FileNotFoundError("no model weights found in '%s'" % dirname)
+        weights = max(numbers)
+    return os.path.join(dirname, "weights_%s.tar" % weights)
+
+
+def _first_set(*candidates):
+    for c in candidates:
+        if c is not None:
+            return c
+
+
+def _remapped_checkpoint(path, model, skip_layers):
+    """Checkpoint tensors under the model's own key names (DataParallel 'module.' prefix removed)."""
+    import torch  # checkpoint deserialisation only
+    saved = torch.load(path, map_location="cpu")
+    out = OrderedDict()
+    for src, dst in match_names(saved, model, skip_layers).items():
+        out[dst.replace("module.", "")] = saved[src]
+    return out
+
+
 def load_model(dirname, device, weights=None, half=None, chunksize=None, batchsize=None,
                overlap=None, quantize=False, use_koi=False, skip_top=False, drop_rate=None,
                drop_rate_bottom=None):
     """
-    config.toml + weights_<N>.tar -> Model on `device`.  Flag > [basecaller] table > default
-    (4000 / 500 / 64); the latest checkpoint unless `weights`; key remap via match_names;
-    koi is never used (XNA alphabets have n_base != 4, util.py:299-301).
+    config.toml + weights_<N>.tar -> Model on `device` (util.py:261-366).  Run parameters:
+    command-line flag, else the [basecaller] table, else 4000 / 500 / 64 (a zero chunksize or
+    batchsize counts as unset, a zero overlap does not); the newest checkpoint unless
+    `weights` names one; keys remapped by match_names; koi is never used (XNA alphabets have
+    n_base != 4, util.py:299-301).
     """
-    import torch  # checkpoint deserialisation only
-
     dirname = _model_dir(dirname)
-    if not weights:
-        weight_files = glob(os.path.join(dirname, "weights_*.tar"))
-        if not weight_files:
-            raise FileNotFoundError("no model weights found in '%s'" % dirname)
-        weights = max(int(re.sub(r".*_([0-9]+).tar", r"\1", w)) for w in weight_files)
-
+    checkpoint = _checkpoint_path(dirname, weights)
     config = toml_lite.load(os.path.join(dirname, "config.toml"))
-    weights = os.path.join(dirname, "weights_%s.tar" % weights)
 
-    bp = config.get("basecaller", {})
-    bp["chunksize"] = chunksize or bp.get("chunksize", 4000)
-    bp["overlap"] = overlap if overlap is not None else bp.get("overlap", 500)
-    bp["batchsize"] = batchsize or bp.get("batchsize", 64)
-    bp["quantize"] = bp.get("quantize") if quantize is None else quantize
-    config["basecaller"] = bp
-    config["encoder"]["drop_rate"] = drop_rate if drop_rate is not None else config["encoder"].get("drop_rate", 0)
-    config["encoder"]["drop_rate_bottom"] = (drop_rate_bottom if drop_rate_bottom is not None
-                                             else config["encoder"].get("drop_rate_bottom", 0))
+    run = config.setdefault("basecaller", {})
+    run["chunksize"] = chunksize or run.get("chunksize", 4000)
+    run["batchsize"] = batchsize or run.get("batchsize", 64)
+    run["overlap"] = _first_set(overlap, run.get("overlap"), 500)
+    run["quantize"] = run.get("quantize") if quantize is None else quantize
+    enc = config["encoder"]
+    enc["drop_rate"] = _first_set(drop_rate, enc.get("drop_rate"), 0)
+    enc["drop_rate_bottom"] = _first_set(drop_rate_bottom, enc.get("drop_rate_bottom"), 0)
 
-    Model = load_symbol(config, "Model")
-    model = Model(config)
+    model = load_symbol(config, "Model")(config)
 
-    if model.seqdist.n_base != 4 and use_koi:
-        sys.stderr.write("[Warning] Setting use_koi to False because n_base != 4.\n")
-        use_koi = False
     if use_koi:
-        sys.stderr.write("[Warning] koi beam search is not part of the MI355X path; using Viterbi.\n")
+        if model.seqdist.n_base != 4:
+            sys.stderr.write("[Warning] Setting use_koi to False because n_base != 4.\n")
+        else:
+            sys.stderr.write("[Warning] koi beam search is not part of the MI355X path; using Viterbi.\n")
 
-    state_dict = torch.load(weights, map_location="cpu")
-    skip_layers = [k for k in model.state_dict().keys() if k.startswith("encoder.9")] if skip_top else []
+    skip_layers = []
     if skip_top:
+        skip_layers = [k for k in model.state_dict() if k.startswith("encoder.9")]
         sys.stderr.write("[WARNING: skipping top layer weights]\n")
-    state_dict = {k2: state_dict[k1] for k1, k2 in match_names(state_dict, model, skip_layers).items()}
-    state_dict = OrderedDict((k.replace("module.", ""), v) for k, v in state_dict.items())
-    missing, unexpected = model.load_state_dict(state_dict, strict=not skip_top)
-    assert unexpected == []
-    assert missing == skip_layers
+    missing, unexpected = model.load_state_dict(
+        _remapped_checkpoint(checkpoint, model, skip_layers), strict=not skip_top)
+    if unexpected or list(missing) != skip_layers:
+        raise RuntimeError("checkpoint does not fit the model: missing %s, unexpected %s"
+                           % (list(missing), list(unexpected)))
 
     if half is None:
         half = half_supported()
