@@ -282,3 +282,39 @@ def test_encoder_f16f8_in1_mode_within_north_star_tolerance():
     assert np.array_equal(out[0], out[1])
     err = np.abs(out[0] - ref)
     assert err.max() < TOL and np.sqrt((err ** 2).mean()) < 2e-4, (err.max(), np.sqrt((err ** 2).mean()))
+
+
+@pytest.mark.parametrize("features,N,L,prec", [
+    (768, 1024, 500, "f16f8"),    # 16 groups: every workgroup serves two (the configs[3] per-GPU launch shape)
+    (768, 600, 300, "f16f8"),     # 10 groups: slots 0-4 serve two groups, ragged last group, spread placement too
+    (768, 150, 400, "f16x3"),     # 3 groups, forced: slot 1 has a single group (blocking path beside the early one)
+    (256, 200, 400, "f16f8"),     # two pieces per step (first piece requested inside the last piece)
+    (384, 200, 400, "f16f8"),     # three pieces: odd count, first piece requested after the last piece instead
+    (128, 330, 400, "f16x3"),     # one piece per step
+    (32, 700, 300, "f16f8"),      # one member per group, 11 groups
+])
+def test_two_groups_per_workgroup_equals_one_launch_per_step(monkeypatch, features, N, L, prec):
+    """lstm_kernel<.., DUAL>: a workgroup serves two chunk groups alternately (XB_LSTM_DUAL: 1 = when the batch needs more
+    groups than one launch holds, 2 = whenever there are two groups).  Same arithmetic, different schedule and hand-off
+    timing: scores must equal the single-group persistent kernel and the one-launch-per-step kernel bit for bit, for both
+    block placements, on repeated calls (warm caches, counters reused)."""
+    nb = 6
+    keys, shapes = encoder_shapes(features, nb)
+    sd = seeded_state_dict(keys, shapes, seed=features + N)
+    x = np.random.default_rng(N).standard_normal((N, L)).astype(np.float32)
+    precision = {"f16f8": _lib.XB_PREC_F16F8, "f16x3": _lib.XB_PREC_F16X3}[prec]
+    outs = {}
+    for name, mode, dual, spread in [("step", 1, "0", "0"), ("single", 2, "0", "0"), ("dual", 2, "2", "0"),
+                                     ("dual_spread", 2, "2", "1"), ("dual_step", 1, "2", "0")]:
+        monkeypatch.setenv("XB_LSTM_DUAL", dual)
+        monkeypatch.setenv("XB_LSTM_SPREAD", spread)
+        ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, precision=precision, lstm_mode=mode)
+        ctx.load_state_dict(sd)
+        for rep in range(2 if mode == 2 else 1):
+            outs[name] = ctx.encode(x)
+        ctx.close()
+    for name in ("single", "dual", "dual_spread", "dual_step"):
+        assert np.array_equal(outs["step"], outs[name]), name
+    picks = sorted({0, 63, 64, N // 2, N - 1})
+    ref = oracle.encode(x[picks], sd, features, nb, 3)
+    assert np.abs(outs["dual"][:, picks] - ref).max() < 2e-4

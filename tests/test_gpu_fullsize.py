@@ -1,8 +1,9 @@
 """GPU: parity at the sizes that bench.py times (BASELINE configs[1..4] per-GPU workloads): features 768, chunksize 10 000,
 batch 512 / 1024 / 2048, 5- and 6-base CRF, through the asynchronous device entry point with two batches in flight.
 
-  * the default schedule (persistent recurrence in 16 time slabs, next layer's GEMM on the second stream, decode on the
-    third) must give the same bytes as the serial order (XB_OVERLAP=0) on EVERY chunk;
+  * the default schedule (persistent recurrence in 16 time slabs, two chunk groups per workgroup when the batch exceeds
+    512 chunks, next layer's GEMM on the second stream, decode on the third) must give the same bytes as the serial order
+    with one group per workgroup (XB_OVERLAP=0, XB_LSTM_DUAL=0) on EVERY chunk;
   * sampled chunks (first / last / the chunk-slab seams 511|512, 1023|1024, 2047) must equal the oracle: its decode of the
     GPU's scores exactly, its fp32 encoder within 2e-4 (north star: 1e-3).
 """
@@ -47,6 +48,7 @@ def test_timed_workload_matches_serial_order_and_oracle(nb, N, monkeypatch):
 
     # ---- default (overlapped) schedule, two batches in flight
     monkeypatch.delenv("XB_OVERLAP", raising=False)
+    monkeypatch.delenv("XB_LSTM_DUAL", raising=False)       # default: two groups per workgroup when N > 512
     ctx, seqs, lens = _run(nb, N, d_signal, 2)
     T = ctx.T
     assert T == L // 5
@@ -65,6 +67,7 @@ def test_timed_workload_matches_serial_order_and_oracle(nb, N, monkeypatch):
 
     # ---- serial order: identical bytes on every chunk
     monkeypatch.setenv("XB_OVERLAP", "0")
+    monkeypatch.setenv("XB_LSTM_DUAL", "0")                 # ... and one group per workgroup, chunk slabs in series
     ctx2, seqs2, lens2 = _run(nb, N, d_signal, 1)
     ctx2.close()
     assert np.array_equal(lens2[0], lens[0])

@@ -21,7 +21,7 @@ keys, shapes = encoder_shapes(F, nb)
 ctx.load_state_dict(seeded_state_dict(keys, shapes, 25))
 x = np.random.default_rng(0).standard_normal((N, L)).astype(np.float32)
 ctx.basecall_chunks(x, "NACGTX")
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 10)()
 ctx.lib.xb_debug_lstm_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 ctx.lib.xb_debug_lstm_stamps(ctx.h, out, 1)
 ctx.set_profiling(True)
@@ -31,8 +31,10 @@ st = ctx.stage_times()
 ctx.lib.xb_debug_lstm_stamps(ctx.h, out, 1)
 names = ["loop / y stores", "gin issue + group wait", "first piece landed", "piece compute (ds_read+MFMA)",
          "pointwise + h stores issued", "stores drained + barrier", "arrive", "piece DMA wait + barrier"]
-steps = 5 * ctx.T
-tot = sum(out)
+gsteps = max(int(out[9]), 1)          # group-steps of workgroup 0 (two per time step when it serves two groups)
+steps = gsteps
+tot = sum(out[:8])
+print("group-steps of workgroup 0: %d, first piece requested early in %d" % (out[9], out[8]))
 print("stage ms:", {k: round(v[0], 2) for k, v in st.items()})
 for i, nme in enumerate(names):
     print("%-30s %10.0f cycles/step  %5.1f %%" % (nme, out[i] / steps, 100.0 * out[i] / max(tot, 1)))

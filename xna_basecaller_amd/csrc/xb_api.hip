@@ -84,6 +84,8 @@ struct xb_ctx {
     unsigned *error = nullptr;
     int lstm_mode = 0;
     int lstm_resident = -1;      // workgroups of the persistent kernel admitted per CU (occupancy query, lazily)
+    int lstm_dual_resident = -1; // the same for the two-groups-per-workgroup variant (larger LDS footprint)
+    int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
     bool profiling = false;
     std::vector<StageEvent> events;
@@ -329,7 +331,9 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
     // ... and the occupancy calculator has to admit at least one such workgroup per CU (queried once per context); a
     // context that cannot keep the persistent kernel resident falls back to one launch per time step
-    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx));
+    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx), 0);
+    if (ctx->lstm_dual_resident < 0) ctx->lstm_dual_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx), 1);
+    const bool dual_ok = ctx->lstm_dual != 0 && ctx->lstm_dual_resident >= 1;
     const int gmax = ctx->lstm_resident >= 1 ? 8 * ((ctx->cu_count / 8) / members) : 0;
     if (mode == 0) mode = gmax >= 1 ? 2 : 1;
     if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
@@ -342,7 +346,11 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
     bool overlapped = false;
     if (mode == 2) {
-        const int slab = gmax > 64 ? 64 * bn : gmax * bn;
+        // a workgroup can serve two groups alternately (lstm_kernel DUAL): a launch then holds 2 * gmax groups, and a
+        // group's hand-off latency is covered by the other group's step.  Used when the batch does not fit gmax groups.
+        const int gslab = gmax > 64 ? 64 : gmax;
+        const bool dual_batch = dual_ok && (ctx->lstm_dual == 2 ? n > bn : n > gslab * bn);
+        const int slab = (dual_batch ? (2 * gslab > 64 ? 64 : 2 * gslab) : gslab) * bn;
         // the exchange buffer and the counters have 64 group slots: with the whole batch inside them every group keeps its
         // own slot across launches, so chunk slabs and time slabs combine freely; a larger batch falls back to one launch
         // per chunk slab over all steps with launch-local slots
@@ -361,6 +369,8 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 for (int n0 = 0; n0 < n; n0 += slab) {
                     p.n0 = n0; p.nslab = (n - n0) < slab ? (n - n0) : slab;
                     p.s_begin = s0; p.s_end = s1; p.persistent = 1;
+                    // a tail slab that fits the single-group launch gets one workgroup per group (twice the CUs at work)
+                    p.dual = dual_batch && (ctx->lstm_dual == 2 ? p.nslab > bn : p.nslab > gslab * bn);
                     // counters are zeroed once per layer (above): consecutive launches follow each other without a memset in
                     // between, so the next launch's workgroups are dispatched the moment the previous one retires
                     p.grp0 = global_groups ? n0 / bn : 0;
@@ -393,6 +403,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
         if (n > 64 * bn) return fail(ctx, XB_ERR_INVALID, "one-launch-per-step LSTM mode handles at most %d chunks per batch", 64 * bn);
         StageScope sc(ctx, XB_STAGE_LSTM_REC, T);
         p.n0 = 0; p.nslab = n; p.persistent = 0;
+        p.dual = dual_ok && ctx->lstm_dual == 2 && n > bn;      // tests only: the per-step variant of the dual kernel
         for (int s = 0; s < T; ++s) {
             p.s_begin = s; p.s_end = s + 1;
             XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
@@ -538,6 +549,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     ctx->ld_nb = (ctx->O + 3) & ~3;
     ctx->lstm_mode = cfg->lstm_mode;
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
+    if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \
@@ -933,7 +945,7 @@ XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_n
 
 #ifdef XB_LSTM_STAMPS
 // diagnostic build only (csrc/Makefile target `diag`): per-phase cycle sums of the LSTM kernel's workgroup 0
-XB_API int xb_debug_lstm_stamps(xb_ctx *ctx, unsigned long long out[8], int reset)
+XB_API int xb_debug_lstm_stamps(xb_ctx *ctx, unsigned long long out[10], int reset)
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipStreamSynchronize(ctx->stream));

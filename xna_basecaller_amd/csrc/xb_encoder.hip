@@ -585,7 +585,7 @@ __device__ __forceinline__ void store16_sc1(void *g, uint4 v)
 // diagnostic build only: per-phase cycle sums of workgroup 0 (never compiled into the product).  The sums are kept
 // in LDS (no vector-memory traffic, so the stamps neither drain vmcnt nor absorb store latencies) and copied out
 // once at the end of the kernel.
-__device__ unsigned long long g_lstm_stamps[8];
+__device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early first-piece requests, 9 = group-steps
 #define XB_STAMP(i)                                                                         \
     do {                                                                                    \
         const unsigned long long now_ = __builtin_readcyclecounter();                       \
@@ -596,7 +596,11 @@ __device__ unsigned long long g_lstm_stamps[8];
 #define XB_STAMP(i) do { } while (0)
 #endif
 
-template <int KS, int NSPLIT>
+// DUAL = true: one workgroup serves TWO groups (g and g + gh) alternately with the same W_hh registers.  A group-step's
+// hand-off (stores reaching L2, the other members' arrivals, the poll) then completes while the workgroup runs the other
+// group's step, the first h piece of the coming group-step is requested before the gate math of the current one, and
+// the gin tile is requested a whole group-step ahead: a launch holds twice the chunks at the same residency.
+template <int KS, int NSPLIT, bool DUAL>
 __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 {
     constexpr int F = KS * 16;
@@ -607,30 +611,38 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     constexpr int SWZ = (CPR & -CPR) - 1;       // XOR mask that stays inside the row
     constexpr int NPARTS = NSPLIT == 1 ? 1 : 2; // hi (, lo or, NSPLIT == 2, the q8 image)
     constexpr int PIECE_BYTES = LG_BN * KP * 2; // one part of one piece
+    constexpr int NG = DUAL ? 2 : 1;            // groups per workgroup
     static_assert(F % KP == 0, "feature size must be a multiple of the piece width");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
     // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
     unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
-    float *sC = reinterpret_cast<float *>(sT + NPARTS * 16 * ST_LD);                // [32 units][64 chunks] cell state
-    // input-projection tile of the step: [64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
-    unsigned char *sG = reinterpret_cast<unsigned char *>(sC + LG_UNITS * LG_BN);
-    int *sFlag = reinterpret_cast<int *>(sG + LG_BN * LG_UNITS * 16);
+    float *sC0 = reinterpret_cast<float *>(sT + NPARTS * 16 * ST_LD);             // [NG][32 units][64 chunks] cell state
+    // input-projection tile of the step: [NG][64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
+    unsigned char *sG0 = reinterpret_cast<unsigned char *>(sC0 + NG * LG_UNITS * LG_BN);
+    int *sFlag = reinterpret_cast<int *>(sG0 + NG * LG_BN * LG_UNITS * 16);
+    // DUAL: the first W_hh fragment lives in LDS (16 B per thread behind the flags and stamps) and is read back at the top of
+    // every group-step: with all 512 registers taken hipcc otherwise parks half of it in scratch, and the reload -- a
+    // scratch load with vmcnt(0) behind it -- would wait for the other group's gin tile and y stores still in flight
+    unsigned char *sW0 = reinterpret_cast<unsigned char *>(sFlag) + 16 + 80;
+    // DUAL, even piece count: the coming group-step's first piece is requested in the DMA-free issue slots of the last piece
+    constexpr bool EIL = DUAL && NP >= 2 && NP % 2 == 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int members = F / LG_UNITS;
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
-    const int g8 = (ngroups + 7) & ~7;
+    const int gh = DUAL ? (ngroups + 1) / 2 : ngroups;          // workgroup slots: slot g serves group g (and g + gh)
+    const int g8 = (gh + 7) & ~7;
     // default: blocks b, b+8, b+16.. (one XCD under round-robin dispatch) form a group -- speed only.
     // spread = 1 deals a group's members over consecutive blocks, i.e. over all XCDs (placement test).
     const int grp = p.spread ? (int)blockIdx.x / members : (int)blockIdx.x % g8;
     const int mb = p.spread ? (int)blockIdx.x % members : (int)blockIdx.x / g8;
-    if (grp >= ngroups) return;
+    if (grp >= gh) return;
+    const bool second = DUAL && grp + gh < ngroups;             // this slot has a second group
     const int N = p.N, T = p.T;
     const int nlast = p.n0 + p.nslab - 1;
-    const int cbase = p.n0 + grp * LG_BN;        // first chunk of the group
     const int hsel = lane >> 5;
     const int ubase = mb * LG_UNITS + wid * 8;   // first unit of this wave
 
@@ -654,28 +666,44 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
     }
     const int sca = 127 - p.w_exp, scb = 127 - 8 - 11;     // E8M0 scale bytes: W image exponent; h image exponent 8 (+11)
+    if (DUAL) *reinterpret_cast<half8 *>(sW0 + tid * 16) = wh[0];
+
+    // ---- the group being served (wave-uniform; re-pointed at every group-step when DUAL)
+    int cbase = 0;                 // first chunk of the group
+    unsigned *cnt = nullptr;       // its arrival counter
+    half_t *xg = nullptr;          // its exchange buffer [parity][part][64 rows][F]
+    float *sC = sC0;
+    unsigned char *sG = sG0;
+    constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
+    auto serve = [&](int gi) {
+        const int g = grp + gi * gh;
+        cbase = p.n0 + g * LG_BN;
+        cnt = p.sync + (size_t)(p.grp0 + g) * 32;
+        xg = p.xh + (size_t)(p.grp0 + g) * (2 * 2 * LG_BN * F);
+        sC = sC0 + gi * (LG_UNITS * LG_BN);
+        sG = sG0 + gi * (LG_BN * LG_UNITS * 16);
+    };
 
     // ---- cell state lives in LDS as [unit][chunk] (the register file is full of W_hh): lane owns
     //      (chunk = 32*nt + (l&31), unit = 8*wid + 2*rg + hsel), only ever touched by that lane
-    int chunk[2];
+#pragma unroll 1
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi == 1 && !second) break;
+        serve(gi);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = cbase + nt * 32 + (lane & 31);
-        chunk[nt] = n <= nlast ? n : nlast;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = cbase + nt * 32 + (lane & 31);
+            const int ch = n <= nlast ? n : nlast;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)] =
-                p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel];
+            for (int rg = 0; rg < 4; ++rg)
+                sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)] =
+                    p.c_state[(size_t)ch * F + ubase + 2 * rg + hsel];
+        }
     }
-
-    unsigned *cnt = p.sync + (size_t)(p.grp0 + grp) * 32;
-    // exchange buffer of this group: [parity][part][64 rows][F]
-    half_t *xg = p.xh + (size_t)(p.grp0 + grp) * (2 * 2 * LG_BN * F);
-    constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
 
 #ifdef XB_LSTM_STAMPS
     unsigned long long *sStamp = reinterpret_cast<unsigned long long *>(sFlag + 4);
-    if (tid == 0) for (int i = 0; i < 8; ++i) sStamp[i] = 0;
+    if (tid == 0) for (int i = 0; i < 10; ++i) sStamp[i] = 0;
     unsigned long long stamp_prev = __builtin_readcyclecounter();
 #endif
     // The input projection of a step (gin: 64 chunks x 128 gate rows x 4 B = 32 KiB per workgroup) is pulled into LDS by
@@ -721,281 +749,386 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             }
         }
     };
-    issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
-    for (int s = p.s_begin; s < p.s_end; ++s) {
-        XB_STAMP(0);   // loop overhead / y stores of the previous step
-        const int t = p.reverse ? T - 1 - s : s;
-        floatx16 acc[2];
 
-        if (s > 0) {
-            if (p.persistent && s > p.s_begin) {
-                // wait until every member of the group has published h_{t-1}
-                if (tid == 0) {
-                    const unsigned target = (unsigned)members * (p.sync_base + (unsigned)(s - p.s_begin));
-                    const unsigned long long t0 = __builtin_readcyclecounter();
-                    int ok = 1;
-                    // the counter is polled back to back (one L2 round trip per poll); the error word and the
-                    // timeout are looked at every 64th poll only
-                    for (unsigned spins = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-                        if ((spins & 63u) == 0 &&
-                            (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                             __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES)) {
-                            __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = 0;
-                            break;
-                        }
-                    }
-                    *sFlag = ok;
-                }
-                __syncthreads();
-                if (*sFlag == 0) return;
-            }
-            XB_STAMP(1);   // gin loads issued + wait for the group
-
-            // h_{t-1} of the group's chunks, piece by piece through LDS (every load sc1).
-            // A piece is NPARTS * CPR wave-instructions of 1 KiB; wave w issues NDMA = NPARTS * CPR / 4 of
-            // them (q = w, w+4, ..), exactly one per MFMA k-step when NSPLIT == 3, so the next piece's
-            // DMA is issued in the shadow of this piece's MFMAs instead of in front of them.
-            constexpr int NDMA = NPARTS * CPR / 4;
-            const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;
-            // instruction q covers cells [64q, 64q+64) = rows RPI*q .. of CPR cells.  For power-of-two CPR the
-            // per-lane part of the source offset is the same for every q of a wave (q = wid mod 4 and
-            // RPI*4 = 0 mod CPR), so it is ONE register; everything else is wave-uniform scalar arithmetic.
-            constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
-            constexpr int RPI = 64 / (POW2 ? CPR : 1);
-            const int lrow = lane / CPR;
-            const int lane_off = POW2 ? lrow * F + (((lane % CPR) ^ ((RPI * wid + lrow) & SWZ)) * 8) : 0;
-            auto issue_dma = [&](int pc, int d) {
-                const int part = NPARTS == 2 ? (d & 1) : 0;
-                const int q = wid + 4 * (NPARTS == 2 ? (d >> 1) : d);
-                unsigned char *dst = sPiece + (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + q * 1024;
-                if (POW2) {
-                    const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
-                    dma16_sc1(base + lane_off, dst);
-                } else {
-                    const int cell = 64 * q + lane;
-                    const int row = cell / CPR, pos = cell % CPR;
-                    dma16_sc1(xprev + part * XPART + (size_t)row * F + pc * KP + (pos ^ (row & SWZ)) * 8, dst);
-                }
-            };
-#pragma unroll
-            for (int d = 0; d < NDMA; ++d) issue_dma(0, d);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first piece and the gin tile (this wave's shares)
-            __syncthreads();
-            XB_STAMP(2);   // first piece landed
-            acc_from_gin(acc);
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc) {
-                const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
-                // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
-                // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use)
-                half8 fh[2][2], fl[2][2];
-                v8i fq[2];
-                auto load_frags = [&](int ks, half8 (&h)[2], half8 (&l)[2]) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const int row = nt * 32 + (lane & 31);
-                        const int pos = (2 * ks + hsel) ^ (row & SWZ);
-                        h[nt] = *reinterpret_cast<const half8 *>(buf + (row * CPR + pos) * 16);
-                        if (NSPLIT == 3) l[nt] = *reinterpret_cast<const half8 *>(buf + PIECE_BYTES + (row * CPR + pos) * 16);
-                    }
-                };
-                // q8 fragment of 32-column block `blk` of the piece: the half OPPOSITE to the W fragment's
-                // (lanes 0-31: the l8 cells 2, 3 of the block; lanes 32-63: the h8 cells 0, 1)
-                auto load_q8 = [&](int blk) {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const int row = nt * 32 + (lane & 31);
-                        const int c0 = 4 * blk + 2 * (1 - hsel);
-                        const unsigned char *rb = buf + PIECE_BYTES + row * CPR * 16;
-                        const v4i x = *reinterpret_cast<const v4i *>(rb + ((c0 ^ (row & SWZ)) * 16));
-                        const v4i y = *reinterpret_cast<const v4i *>(rb + (((c0 + 1) ^ (row & SWZ)) * 16));
-                        fq[nt] = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
-                };
-                load_frags(0, fh[0], fl[0]);
-#pragma unroll
-                for (int ks = 0; ks < KSP; ++ks) {
-                    const int kg = pc * KSP + ks;
-                    if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
-                    if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        if (NSPLIT == 3) {
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fl[ks & 1][nt], acc[nt], 0, 0, 0);
-                        }
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
-                    }
-                    if (NSPLIT == 2 && (ks & 1) == 1) {
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[kg >> 1], fq[nt], acc[nt], 0, 0, 0, sca, 0, scb);
-                    }
-                    // two per k-step so that the last one is issued by mid-piece and has landed at the barrier
-                    if (pc + 1 < NP) {
-                        if (2 * ks < NDMA) issue_dma(pc + 1, 2 * ks);
-                        if (2 * ks + 1 < NDMA) issue_dma(pc + 1, 2 * ks + 1);
-                    }
-
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
-                __syncthreads();
-                XB_STAMP(7);   // piece DMA wait + barrier
-            }
-        }
-
-        if (s == 0) {      // no recurrent term in the very first step: the accumulators are the input projection
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            acc_from_gin(acc);
-        }
-
-        // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
-        // with the other half-wave's units so that each lane packs two ADJACENT units into one dword, written to
-        // the [pair][chunk] staging (consecutive lanes -> consecutive dwords: conflict-free).
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            unsigned phi[4], plo[4];
-            float hq[4], lq[4];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
-                const float fg = fast_sigmoid(acc[nt][4 * rg + 1]);
-                const float gg = fast_tanh(acc[nt][4 * rg + 2]);
-                const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
-                float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
-                const float cn = fg * *cp + ig * gg;
-                *cp = cn;
-                const float hv = og * fast_tanh(cn);
-                half_t hi, lo;
-                split_f16(hv, hi, lo);
-                phi[rg] = (unsigned)__builtin_bit_cast(unsigned short, hi);
-                plo[rg] = (unsigned)__builtin_bit_cast(unsigned short, lo);
-                hq[rg] = (float)hi * 256.0f;                   // |h| < 1: below the e4m3 maximum by construction
-                lq[rg] = (hv - (float)hi) * 524288.0f;         // 2^19; |residual| <= 2^-11 |hi|
-            }
-            // lanes < 32 hold even units v[rg] = unit 2rg, lanes >= 32 the odd ones v[rg] = unit 2rg+1.
-            // v_permlane32_swap(vdst, src) exchanges vdst's upper half-wave with src's lower half-wave, so
-            //   swap(v[0], v[2]) -> {r[0], r[1]} = low lanes {unit 0, unit 1}, high lanes {unit 4, unit 5}
-            //   swap(v[1], v[3]) -> low lanes {unit 2, unit 3}, high lanes {unit 6, unit 7}
-#pragma unroll
-            for (int part = 0; part < (NSPLIT == 3 ? 2 : 1); ++part) {
-                unsigned *v = part == 0 ? phi : plo;
-                auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
-                const unsigned e0 = r0[0], o0 = r0[1], e1 = r1[0], o1 = r1[1];
-                const int pr = wid * 4 + hsel * 2;                  // first unit pair of this lane
-                unsigned *dst = sT + part * 16 * ST_LD + nt * 32 + (lane & 31);
-                dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
-                dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
-            }
-            if (NSPLIT == 2) {
-                // q8 image of the 32 units: 16 dword rows in the place of the lo staging -- rows 0..7 the h8 bytes of unit
-                // quads 0..7, rows 8..15 their l8 bytes, so the 16-byte cell reads below need no change.
-                // X = {h8(u_a), h8(u_b), l8(u_a), l8(u_b)} of this lane's units (rg 0, 1), Y of (rg 2, 3); after the swap
-                // low lanes hold units (0,2) / (1,3), high lanes (4,6) / (5,7): one byte permute per image interleaves them.
-                unsigned X = fp8_pair<false>(hq[0], hq[1], 0u), Y = fp8_pair<false>(hq[2], hq[3], 0u);
-                X = fp8_pair<true>(lq[0], lq[1], X);
-                Y = fp8_pair<true>(lq[2], lq[3], Y);
-                auto r = __builtin_amdgcn_permlane32_swap(X, Y, false, false);
-                const unsigned r0 = r[0], r1 = r[1];
-                unsigned *dst = sT + 16 * ST_LD + nt * 32 + (lane & 31);
-                dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
-                dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
-            }
-        }
-        __syncthreads();
-        // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part (cell = 4 unit pairs of one chunk)
-        const int orow = tid >> 2, occ = tid & 3;
-        uint4 vhi, vlo = make_uint4(0, 0, 0, 0);
-        {
-            const unsigned *src = sT + (occ * 4) * ST_LD + orow;
-            vhi = make_uint4(src[0], src[ST_LD], src[2 * ST_LD], src[3 * ST_LD]);
-            if (NSPLIT != 1) {
-                const unsigned *sl = src + 16 * ST_LD;
-                vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
-            }
-        }
-        if (s + 1 < T) {
-            // publish h_t for the group -- also on the last step of a launch: the next launch (next step, or next time
-            // slab) starts from the exchange buffer (rows beyond the slab are scratch rows of the exchange buffer)
-            half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
-            store16_sc1(xcur, vhi);
-            if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
-        }
-        XB_STAMP(4);   // pointwise + exchange stores issued
-        if (p.persistent && s + 1 < p.s_end) {
-            // next step's gin tile (eight LDS-DMAs per wave), then every storing wave drains its exchange stores: all but
-            // the eight youngest operations (raw barrier: __syncthreads() would drain the DMAs as well; the LDS reads of
-            // the staging are retired here)
-            __builtin_amdgcn_sched_barrier(0);
-            issue_gin(p.reverse ? T - 2 - s : s + 1);
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            XB_STAMP(5);   // stores drained
-            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            XB_STAMP(6);   // arrive
+    // h_{t-1} of a group's chunks comes piece by piece through LDS (every load sc1).
+    // A piece is NPARTS * CPR wave-instructions of 1 KiB; wave w issues NDMA = NPARTS * CPR / 4 of
+    // them (q = w, w+4, ..), exactly one per MFMA k-step when NSPLIT == 3, so the next piece's
+    // DMA is issued in the shadow of this piece's MFMAs instead of in front of them.
+    // Instruction q covers cells [64q, 64q+64) = rows RPI*q .. of CPR cells.  For power-of-two CPR the
+    // per-lane part of the source offset is the same for every q of a wave (q = wid mod 4 and
+    // RPI*4 = 0 mod CPR), so it is ONE register; everything else is wave-uniform scalar arithmetic.
+    constexpr int NDMA = NPARTS * CPR / 4;
+    constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+    constexpr int RPI = 64 / (POW2 ? CPR : 1);
+    int lane_off_step = 0;      // computed once per (group-)step: as a value kept across the gate math it would be spilled
+    auto issue_dma = [&](const half_t *xprev, int pc, int d) {
+        const int lo = lane;
+        const int lane_off = lane_off_step;
+        const int part = NPARTS == 2 ? (d & 1) : 0;
+        const int q = wid + 4 * (NPARTS == 2 ? (d >> 1) : d);
+        unsigned char *dst = sPiece + (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + q * 1024;
+        if (POW2) {
+            const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
+            dma16_sc1(base + lane_off, dst);
         } else {
-            __syncthreads();   // sT is rewritten next step
+            const int cell = 64 * q + lo;
+            const int row = cell / CPR, pos = cell % CPR;
+            dma16_sc1(xprev + part * XPART + (size_t)row * F + pc * KP + (pos ^ (row & SWZ)) * 8, dst);
         }
-        // layer output for the next layer: plain stores, nobody in this launch reads them
-        // (address recomputed from the thread index here: a value kept across the loop gets spilled, and its reload -- a
-        // scratch load with a vmcnt(0) behind it -- would wait for the gin DMAs just issued)
-        {
-            int to = tid;
-            asm volatile("" : "+v"(to));
-            const int n = cbase + (to >> 2);
-            if (n <= nlast) {
-                const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
-                *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
-                *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+    };
+
+#pragma unroll 1
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi == 1 && !second) break;
+        serve(gi);
+        issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
+    }
+    bool early = false;     // DUAL: the first piece of the coming group-step was requested during the previous one
+    for (int s = p.s_begin; s < p.s_end; ++s) {
+        const int t = p.reverse ? T - 1 - s : s;
+#pragma unroll 1
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi == 1 && !second) break;
+            if (DUAL) serve(gi);
+            XB_STAMP(0);   // loop overhead / y stores of the previous group-step
+            floatx16 acc[2];
+            // DUAL: the group-step this workgroup serves next, whether it has a recurrent term (s > 0) and whether its
+            // group has to be polled first (not in the first step of a launch: the previous launch has retired)
+            const int ngi = (DUAL && gi == 0 && second) ? 1 : 0;
+            const int ns = (DUAL && gi == 0 && second) ? s : s + 1;
+            const bool nxt_h = DUAL && ns < p.s_end && ns > 0 && s > 0;
+            const bool nxt_poll = p.persistent && ns > p.s_begin;
+            unsigned *ncnt = p.sync + (size_t)(p.grp0 + grp + ngi * gh) * 32;
+            const unsigned ntarget = (unsigned)members * (p.sync_base + (unsigned)(ns - p.s_begin));
+            unsigned seen = 0;
+            const half_t *xnext = p.xh + (size_t)(p.grp0 + grp + ngi * gh) * (2 * 2 * LG_BN * F) + (size_t)((ns - 1) & 1) * XPAR;
+            const bool was_early = early;
+            early = false;
+            int go = 0;         // EIL: request the coming group-step's first piece during the last piece
+
+            if (s > 0) {
+                const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;
+                {
+                    int lo = lane;
+                    if (DUAL) asm volatile("" : "+v"(lo));
+                    const int lrow = lo / CPR;
+                    lane_off_step = POW2 ? lrow * F + (((lo % CPR) ^ ((RPI * wid + lrow) & SWZ)) * 8) : 0;
+                }
+                if (!DUAL || !was_early) {
+                    if (p.persistent && s > p.s_begin) {
+                        // wait until every member of the group has published h_{t-1}
+                        if (tid == 0) {
+                            const unsigned target = (unsigned)members * (p.sync_base + (unsigned)(s - p.s_begin));
+                            const unsigned long long t0 = __builtin_readcyclecounter();
+                            int ok = 1;
+                            // the counter is polled back to back (one L2 round trip per poll); the error word and the
+                            // timeout are looked at every 64th poll only
+                            for (unsigned spins = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+                                if ((spins & 63u) == 0 &&
+                                    (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                     __builtin_readcyclecounter() - t0 > LG_SPIN_CYCLES)) {
+                                    __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = 0;
+                                    break;
+                                }
+                            }
+                            *sFlag = ok;
+                        }
+                        __syncthreads();
+                        if (*sFlag == 0) return;
+                    }
+                    XB_STAMP(1);   // gin loads issued + wait for the group
+#pragma unroll
+                    for (int d = 0; d < NDMA; ++d) issue_dma(xprev, 0, d);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first piece and the gin tile (this wave's shares)
+                    __syncthreads();
+                }
+                // (early: the drain wait and barrier that ended the previous group-step covered the first piece and this
+                //  group's gin tile, both older than the exchange stores drained there)
+                XB_STAMP(2);   // first piece landed
+                half8 w0 = wh[0];
+                if (DUAL) {
+                    int to = tid;
+                    asm volatile("" : "+v"(to));
+                    w0 = *reinterpret_cast<const half8 *>(sW0 + to * 16);
+                }
+                acc_from_gin(acc);
+                // lane byte offsets of the B-fragment cells inside a piece part (one register per k-step / q8 cell; the
+                // piece buffer, the part and the column tile are immediates)
+                unsigned fa[KSP], qa[KSP / 2 > 0 ? KSP / 2 : 1][2];
+                {
+                    int lo = lane;
+                    asm volatile("" : "+v"(lo));
+                    const unsigned r = (unsigned)lo & 31u, hs = (unsigned)lo >> 5;
+#pragma unroll
+                    for (int ks = 0; ks < KSP; ++ks) fa[ks] = (r * CPR + ((2 * ks + hs) ^ (r & SWZ))) * 16;
+#pragma unroll
+                    for (int b = 0; b < KSP / 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) qa[b][j] = (r * CPR + ((4 * b + 2 * (1 - hs) + j) ^ (r & SWZ))) * 16;
+                }
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
+                    // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
+                    // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use)
+                    half8 fh[2][2], fl[2][2];
+                    v8i fq[2];
+                    auto load_frags = [&](int ks, half8 (&h)[2], half8 (&l)[2]) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            // row = 32 nt + (lane & 31); row & SWZ does not depend on nt, so nt is an immediate offset
+                            const unsigned char *a = buf + nt * (32 * CPR * 16) + fa[ks];
+                            h[nt] = *reinterpret_cast<const half8 *>(a);
+                            if (NSPLIT == 3) l[nt] = *reinterpret_cast<const half8 *>(a + PIECE_BYTES);
+                        }
+                    };
+                    // q8 fragment of 32-column block `blk` of the piece: the half OPPOSITE to the W fragment's
+                    // (lanes 0-31: the l8 cells 2, 3 of the block; lanes 32-63: the h8 cells 0, 1)
+                    auto load_q8 = [&](int blk) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const unsigned char *rb = buf + PIECE_BYTES + nt * (32 * CPR * 16);
+                            const v4i x = *reinterpret_cast<const v4i *>(rb + qa[blk][0]);
+                            const v4i y = *reinterpret_cast<const v4i *>(rb + qa[blk][1]);
+                            fq[nt] = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    };
+                    load_frags(0, fh[0], fl[0]);
+                    // DUAL: has the group of the coming group-step arrived?  One look at its counter (its members had a whole
+                    // group-step for it) at the start of the piece whose closing barrier publishes the answer: the last
+                    // piece, or (EIL) the one before it.
+                    constexpr int PCHK = EIL ? NP - 2 : NP - 1;
+                    if (DUAL && pc == PCHK && nxt_h && nxt_poll && tid == 0)
+                        seen = __hip_atomic_load(ncnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (EIL && pc == NP - 1) go = __builtin_amdgcn_readfirstlane(nxt_h ? sFlag[1] : 0);
+#pragma unroll
+                    for (int ks = 0; ks < KSP; ++ks) {
+                        const int kg = pc * KSP + ks;
+                        if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
+                        if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            if (NSPLIT == 3) {
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fl[ks & 1][nt], acc[nt], 0, 0, 0);
+                            }
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kg == 0 ? w0 : wh[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                        }
+                        if (NSPLIT == 2 && (ks & 1) == 1) {
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[kg >> 1], fq[nt], acc[nt], 0, 0, 0, sca, 0, scb);
+                        }
+                        // two per k-step so that the last one is issued by mid-piece and has landed at the barrier
+                        if (pc + 1 < NP) {
+                            if (2 * ks < NDMA) issue_dma(xprev, pc + 1, 2 * ks);
+                            if (2 * ks + 1 < NDMA) issue_dma(xprev, pc + 1, 2 * ks + 1);
+                        } else if (EIL && go) {
+                            if (2 * ks < NDMA) issue_dma(xnext, 0, 2 * ks);
+                            if (2 * ks + 1 < NDMA) issue_dma(xnext, 0, 2 * ks + 1);
+                        }
+
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
+                    if (DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
+                    __syncthreads();
+                    XB_STAMP(7);   // piece DMA wait + barrier
+                }
+            }
+
+            if (s == 0) {      // no recurrent term in the very first step: the accumulators are the input projection
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                acc_from_gin(acc);
+            }
+
+            // DUAL: request the first piece of the coming group-step now -- it lands behind the gate math, and the drain
+            // wait below (everything but the eight youngest operations) covers it
+            if (EIL) {
+                early = go != 0;    // requested inside the last piece; its closing wait and barrier have landed it
+            } else if (DUAL && nxt_h && sFlag[1] != 0) {
+#pragma unroll
+                for (int d = 0; d < NDMA; ++d) issue_dma(xnext, 0, d);
+                early = true;
+            }
+#ifdef XB_LSTM_STAMPS
+            if (tid == 0) { sStamp[8] += early ? 1 : 0; sStamp[9] += 1; }
+#endif
+
+            // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
+            // with the other half-wave's units so that each lane packs two ADJACENT units into one dword, written to
+            // the [pair][chunk] staging (consecutive lanes -> consecutive dwords: conflict-free).
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                unsigned phi[4], plo[4];
+                float hq[4], lq[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
+                    const float fg = fast_sigmoid(acc[nt][4 * rg + 1]);
+                    const float gg = fast_tanh(acc[nt][4 * rg + 2]);
+                    const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
+                    float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
+                    const float cn = fg * *cp + ig * gg;
+                    *cp = cn;
+                    const float hv = og * fast_tanh(cn);
+                    half_t hi, lo;
+                    split_f16(hv, hi, lo);
+                    phi[rg] = (unsigned)__builtin_bit_cast(unsigned short, hi);
+                    plo[rg] = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                    hq[rg] = (float)hi * 256.0f;                   // |h| < 1: below the e4m3 maximum by construction
+                    lq[rg] = (hv - (float)hi) * 524288.0f;         // 2^19; |residual| <= 2^-11 |hi|
+                }
+                // lanes < 32 hold even units v[rg] = unit 2rg, lanes >= 32 the odd ones v[rg] = unit 2rg+1.
+                // v_permlane32_swap(vdst, src) exchanges vdst's upper half-wave with src's lower half-wave, so
+                //   swap(v[0], v[2]) -> {r[0], r[1]} = low lanes {unit 0, unit 1}, high lanes {unit 4, unit 5}
+                //   swap(v[1], v[3]) -> low lanes {unit 2, unit 3}, high lanes {unit 6, unit 7}
+#pragma unroll
+                for (int part = 0; part < (NSPLIT == 3 ? 2 : 1); ++part) {
+                    unsigned *v = part == 0 ? phi : plo;
+                    auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+                    const unsigned e0 = r0[0], o0 = r0[1], e1 = r1[0], o1 = r1[1];
+                    const int pr = wid * 4 + hsel * 2;                  // first unit pair of this lane
+                    unsigned *dst = sT + part * 16 * ST_LD + nt * 32 + (lane & 31);
+                    dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
+                    dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
+                }
+                if (NSPLIT == 2) {
+                    // q8 image of the 32 units: 16 dword rows in the place of the lo staging -- rows 0..7 the h8 bytes of unit
+                    // quads 0..7, rows 8..15 their l8 bytes, so the 16-byte cell reads below need no change.
+                    // X = {h8(u_a), h8(u_b), l8(u_a), l8(u_b)} of this lane's units (rg 0, 1), Y of (rg 2, 3); after the swap
+                    // low lanes hold units (0,2) / (1,3), high lanes (4,6) / (5,7): one byte permute per image interleaves them.
+                    unsigned X = fp8_pair<false>(hq[0], hq[1], 0u), Y = fp8_pair<false>(hq[2], hq[3], 0u);
+                    X = fp8_pair<true>(lq[0], lq[1], X);
+                    Y = fp8_pair<true>(lq[2], lq[3], Y);
+                    auto r = __builtin_amdgcn_permlane32_swap(X, Y, false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    unsigned *dst = sT + 16 * ST_LD + nt * 32 + (lane & 31);
+                    dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+                    dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+                }
+            }
+            if (DUAL) {
+                // raw barrier: __syncthreads() would drain the first piece just requested
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
+            // 64 rows x 64 B per part = 256 cells of 16 B: one per thread per part (cell = 4 unit pairs of one chunk)
+            const int orow = tid >> 2, occ = tid & 3;
+            uint4 vhi, vlo = make_uint4(0, 0, 0, 0);
+            {
+                const unsigned *src = sT + (occ * 4) * ST_LD + orow;
+                vhi = make_uint4(src[0], src[ST_LD], src[2 * ST_LD], src[3 * ST_LD]);
+                if (NSPLIT != 1) {
+                    const unsigned *sl = src + 16 * ST_LD;
+                    vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
+                }
+            }
+            if (s + 1 < T) {
+                // publish h_t for the group -- also on the last step of a launch: the next launch (next step, or next time
+                // slab) starts from the exchange buffer (rows beyond the slab are scratch rows of the exchange buffer)
+                half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
+                store16_sc1(xcur, vhi);
+                if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
+            }
+            XB_STAMP(4);   // pointwise + exchange stores issued
+            if (p.persistent && s + 1 < p.s_end) {
+                // next step's gin tile (eight LDS-DMAs per wave), then every storing wave drains its exchange stores: all but
+                // the eight youngest operations (raw barrier: __syncthreads() would drain the DMAs as well; the LDS reads of
+                // the staging are retired here)
+                __builtin_amdgcn_sched_barrier(0);
+                issue_gin(p.reverse ? T - 2 - s : s + 1);
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                XB_STAMP(5);   // stores drained
+                if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                XB_STAMP(6);   // arrive
+            } else {
+                __syncthreads();   // sT is rewritten next step (this also lands an early first piece)
+            }
+            // layer output for the next layer: plain stores, nobody in this launch reads them
+            // (address recomputed from the thread index here: a value kept across the loop gets spilled, and its reload -- a
+            // scratch load with a vmcnt(0) behind it -- would wait for the gin DMAs just issued)
+            {
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                const int n = cbase + (to >> 2);
+                if (n <= nlast) {
+                    const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
+                    *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
+                    *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+                }
             }
         }
     }
 
 #ifdef XB_LSTM_STAMPS
-    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_lstm_stamps[i] += sStamp[i];
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 10; ++i) g_lstm_stamps[i] += sStamp[i];
 #endif
+#pragma unroll 1
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi == 1 && !second) break;
+        serve(gi);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-        if (cbase + nt * 32 + (lane & 31) <= nlast)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = cbase + nt * 32 + (lane & 31);
+            if (n <= nlast)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                p.c_state[(size_t)chunk[nt] * F + ubase + 2 * rg + hsel] =
-                    sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)];
+                for (int rg = 0; rg < 4; ++rg)
+                    p.c_state[(size_t)n * F + ubase + 2 * rg + hsel] =
+                        sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)];
+        }
+    }
+}
+
+// dynamic LDS of lstm_kernel<KS, nsplit, dual>
+template <int KS>
+static size_t lstm_lds_bytes(int nsplit, bool dual)
+{
+    constexpr int F = KS * 16;
+    constexpr int KP = F < 128 ? F : 128;
+    const int nparts = nsplit == 1 ? 1 : 2;
+    const int ng = dual ? 2 : 1;
+    return (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
+           (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + (dual ? 256 * 16 : 0);
+}
+
+template <int KS, int NSPLIT, bool DUAL>
+hipError_t launch_lstm_v(const xb::LstmParams &p, dim3 grid, size_t lds, hipStream_t stream)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, NSPLIT, DUAL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((lstm_kernel<KS, NSPLIT, DUAL>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
 }
 
 template <int KS>
 hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 {
     constexpr int F = KS * 16;
-    constexpr int KP = F < 128 ? F : 128;
-    const int nparts = p.nsplit == 1 ? 1 : 2;
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
-    const int g8 = (ngroups + 7) & ~7;
+    const bool dual = p.dual != 0;
+    const int gh = dual ? (ngroups + 1) / 2 : ngroups;      // workgroup slots (lstm_kernel)
+    const int g8 = (gh + 7) & ~7;
     const int members = F / LG_UNITS;
-    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-                       sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16 + 16 + 80;
-    dim3 grid(g8 * members), block(256);
-    if (p.nsplit == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((lstm_kernel<KS, 3>), grid, block, lds, stream, p);
-    } else if (p.nsplit == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((lstm_kernel<KS, 2>), grid, block, lds, stream, p);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((lstm_kernel<KS, 1>), grid, block, lds, stream, p);
+    const size_t lds = lstm_lds_bytes<KS>(p.nsplit, dual);
+    const dim3 grid(g8 * members);
+    if (dual) {
+        if (p.nsplit == 3) return launch_lstm_v<KS, 3, true>(p, grid, lds, stream);
+        if (p.nsplit == 2) return launch_lstm_v<KS, 2, true>(p, grid, lds, stream);
+        return launch_lstm_v<KS, 1, true>(p, grid, lds, stream);
     }
-    return hipGetLastError();
+    if (p.nsplit == 3) return launch_lstm_v<KS, 3, false>(p, grid, lds, stream);
+    if (p.nsplit == 2) return launch_lstm_v<KS, 2, false>(p, grid, lds, stream);
+    return launch_lstm_v<KS, 1, false>(p, grid, lds, stream);
 }
 
 template <int EPI, int NSPLIT>
@@ -1052,11 +1185,11 @@ hipError_t launch_gemm(const GemmParams &p, int epilogue, hipStream_t stream)
 }
 
 #ifdef XB_LSTM_STAMPS
-void lstm_read_stamps(unsigned long long out[8], bool reset)
+void lstm_read_stamps(unsigned long long out[10], bool reset)
 {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_stamps), sizeof(unsigned long long) * 8);
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_stamps), sizeof(unsigned long long) * 10);
     if (reset) {
-        unsigned long long z[8] = {};
+        unsigned long long z[10] = {};
         hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamps), z, sizeof z);
     }
 }
@@ -1069,40 +1202,41 @@ bool lstm_supported_features(int F)
     default: return false;
     }
 }
-template <int KS>
-static int lstm_occupancy_ks(int nsplit)
+template <int KS, int NSPLIT, bool DUAL>
+static int lstm_occupancy_v(size_t lds)
 {
-    constexpr int F = KS * 16;
-    constexpr int KP = F < 128 ? F : 128;
-    const int nparts = nsplit == 1 ? 1 : 2;
-    const size_t lds = (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-                       sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16 + 16 + 80;
     int nb = 0;
-    hipError_t e;
-    if (nsplit == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 3>, 256, lds);
-    } else if (nsplit == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 2>, 256, lds);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, 1>, 256, lds);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, NSPLIT, DUAL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_kernel<KS, NSPLIT, DUAL>, 256, lds);
     return e == hipSuccess ? nb : 0;
 }
 
-int lstm_resident_per_cu(int F, int nsplit)
+template <int KS>
+static int lstm_occupancy_ks(int nsplit, bool dual)
+{
+    const size_t lds = lstm_lds_bytes<KS>(nsplit, dual);
+    if (dual) {
+        if (nsplit == 3) return lstm_occupancy_v<KS, 3, true>(lds);
+        if (nsplit == 2) return lstm_occupancy_v<KS, 2, true>(lds);
+        return lstm_occupancy_v<KS, 1, true>(lds);
+    }
+    if (nsplit == 3) return lstm_occupancy_v<KS, 3, false>(lds);
+    if (nsplit == 2) return lstm_occupancy_v<KS, 2, false>(lds);
+    return lstm_occupancy_v<KS, 1, false>(lds);
+}
+
+int lstm_resident_per_cu(int F, int nsplit, int dual)
 {
     switch (F / 16) {
-    case 2: return lstm_occupancy_ks<2>(nsplit);
-    case 4: return lstm_occupancy_ks<4>(nsplit);
-    case 6: return lstm_occupancy_ks<6>(nsplit);
-    case 8: return lstm_occupancy_ks<8>(nsplit);
-    case 16: return lstm_occupancy_ks<16>(nsplit);
-    case 24: return lstm_occupancy_ks<24>(nsplit);
-    case 32: return lstm_occupancy_ks<32>(nsplit);
-    case 48: return lstm_occupancy_ks<48>(nsplit);
+    case 2: return lstm_occupancy_ks<2>(nsplit, dual != 0);
+    case 4: return lstm_occupancy_ks<4>(nsplit, dual != 0);
+    case 6: return lstm_occupancy_ks<6>(nsplit, dual != 0);
+    case 8: return lstm_occupancy_ks<8>(nsplit, dual != 0);
+    case 16: return lstm_occupancy_ks<16>(nsplit, dual != 0);
+    case 24: return lstm_occupancy_ks<24>(nsplit, dual != 0);
+    case 32: return lstm_occupancy_ks<32>(nsplit, dual != 0);
+    case 48: return lstm_occupancy_ks<48>(nsplit, dual != 0);
     default: return 0;
     }
 }

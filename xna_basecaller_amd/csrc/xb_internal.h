@@ -98,17 +98,18 @@ struct LstmParams {
     int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8)
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
+    int dual;                    // 1: a workgroup serves two groups alternately (a launch then holds twice the groups)
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
 // workgroups of the persistent kernel the occupancy calculator admits per CU for feature size F (0: the kernel cannot be
 // resident at all, e.g. LDS or registers taken by another tenant's limits); the persistent mode needs >= 1
-int lstm_resident_per_cu(int F, int nsplit);
+int lstm_resident_per_cu(int F, int nsplit, int dual);
 int lstm_members(int F);
 int lstm_group_chunks();
 bool lstm_supported_features(int F);
 #ifdef XB_LSTM_STAMPS
-void lstm_read_stamps(unsigned long long out[8], bool reset);   // diagnostic build only
+void lstm_read_stamps(unsigned long long out[10], bool reset);   // diagnostic build only
 #endif
 
 }  // namespace xb
