@@ -182,7 +182,9 @@ def main():
     flop_launch = 5 * 2.0 * (4 * F) * F * T * N / max(rec_launches / K, 1)   # a layer may run as several time-slab launches
     rec_avg_s = 1e-3 * rec_ms / max(rec_launches, 1)
     rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
-    roofline = {"kernel": "lstm_kernel<%d,%d>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2}[prec]), "bound": "mfma",
+    dual = N > 512 and os.environ.get("XB_LSTM_DUAL", "1") != "0"     # two chunk groups per workgroup
+    roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2}[prec], "true" if dual else "false"),
+                "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
                 "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision),
@@ -210,7 +212,8 @@ def main():
                   3: "f32 (as f16f8, LSTM input projections f16 MFMA only, f32 accumulate; |score err| <= 1e-3; CRF decode f32)"}[prec],
         "data": "synthetic N(0,1) signal chunks generated in HBM; seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout",
         "config": {"workload": "BASELINE configs[%s]: %d-base CRF (S=%d, C=%d), chunksize %d, batch %d per GPU, features %d"
-                               % ({5: "1", 6: "2"}.get(nb, "-"), nb, S, S * E, L, N, F),
+                               % ({(5, 512): "1", (6, 512): "2", (6, 1024): "3] per-GPU workload [1 of 8 ranks",
+                                   (6, 2048): "4] per-GPU workload [1 of 8 ranks"}.get((nb, N), "-"), nb, S, S * E, L, N, F),
                    "n_base": nb, "chunksize": L, "batch_per_gpu": N, "T": T, "parallelism": "reads sharded x%d" % world,
                    "collective": "all_gather of packed sequences per step, on a side stream one step late" if world > 1 else "none"},
         "roofline": roofline, "roofline_decode": roofline_decode,

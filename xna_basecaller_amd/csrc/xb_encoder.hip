@@ -628,6 +628,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     unsigned char *sW0 = reinterpret_cast<unsigned char *>(sFlag) + 16 + 80;
     // DUAL, even piece count: the coming group-step's first piece is requested in the DMA-free issue slots of the last piece
     constexpr bool EIL = DUAL && NP >= 2 && NP % 2 == 0;
+#ifdef XB_LSTM_STAMPS
+    constexpr bool PARK = true;         // the stamp bookkeeping costs the single-group kernel the same registers
+#else
+    constexpr bool PARK = DUAL;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
     }
     const int sca = 127 - p.w_exp, scb = 127 - 8 - 11;     // E8M0 scale bytes: W image exponent; h image exponent 8 (+11)
-    if (DUAL) *reinterpret_cast<half8 *>(sW0 + tid * 16) = wh[0];
+    if (PARK) *reinterpret_cast<half8 *>(sW0 + tid * 16) = wh[0];
 
     // ---- the group being served (wave-uniform; re-pointed at every group-step when DUAL)
     int cbase = 0;                 // first chunk of the group
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;
                 {
                     int lo = lane;
-                    if (DUAL) asm volatile("" : "+v"(lo));
+                    if (PARK) asm volatile("" : "+v"(lo));
                     const int lrow = lo / CPR;
                     lane_off_step = POW2 ? lrow * F + (((lo % CPR) ^ ((RPI * wid + lrow) & SWZ)) * 8) : 0;
                 }
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 //  group's gin tile, both older than the exchange stores drained there)
                 XB_STAMP(2);   // first piece landed
                 half8 w0 = wh[0];
-                if (DUAL) {
+                if (PARK) {
                     int to = tid;
                     asm volatile("" : "+v"(to));
                     w0 = *reinterpret_cast<const half8 *>(sW0 + to * 16);
@@ -1098,7 +1103,7 @@ static size_t lstm_lds_bytes(int nsplit, bool dual)
     const int nparts = nsplit == 1 ? 1 : 2;
     const int ng = dual ? 2 : 1;
     return (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-           (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + (dual ? 256 * 16 : 0);
+           (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + 256 * 16;
 }
 
 template <int KS, int NSPLIT, bool DUAL>
