@@ -127,6 +127,15 @@ XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_bla
 XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank,
                          const char *alphabet, int8_t *d_labels, int8_t *d_seq, int32_t *d_seq_len);
 
+/*
+ * CTC_CRF.logZ (crf/model.py:41-46; seqdist sparse.logZ with the Log semiring): the partition function of every chunk,
+ * logZ[n] = logsumexp_j alpha_T[j] of the forward recursion alpha_0 = 0, alpha_{t+1}[j] = logsumexp_k(M[t,j,k] +
+ * alpha_t[idx[j,k]]) -- the first sweep of the decode, on its own.  scores as for xb_decode; logz (n) fp32.
+ * (`normalise(scores)` of crf/model.py:48-49 is scores - logZ[:, None] / T on the caller's side.)
+ */
+XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz);
+XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz);
+
 /* compute_scores (crf/basecall.py:27-82), viterbi branch: encode + decode without materialising
  * the blank column or copying scores off the device. */
 XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet,

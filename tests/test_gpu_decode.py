@@ -165,3 +165,42 @@ def test_decode_random_shapes(monkeypatch):
         _check(ctx, sc, nb, "NACGTXY"[:nb + 1], blank=None if with_blank else 2.0)
     for ctx in ctxs.values():
         ctx.close()
+
+
+@pytest.mark.parametrize("nb,with_blank,T,N", [(4, True, 77, 3), (5, False, 400, 6), (6, True, 2000, 9), (6, False, 1, 2)])
+def test_crf_logz_is_the_oracles_bit_for_bit(nb, with_blank, T, N):
+    """xb_crf_logz = CTC_CRF.logZ (crf/model.py:41-46): the Log forward sweep alone.  Same contract arithmetic as the
+    oracle, so the partition function must have the same bits; it must also be what the full decode normalises with
+    (posteriors of one step sum to 1 -- checked in the oracle tier) and be unchanged by a decode in between."""
+    import torch
+    ctx = _ctx(nb, T, N)
+    sc = random_scores(T, N, nb, seed=3 * nb + T, with_blank=with_blank)
+    ref = oracle.decode(sc, nb, 3, blank_score=None if with_blank else 2.0, want=("logz",))["logz"]
+    got = ctx.crf_logz(sc)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    ctx.decode(sc, "NACGTXY"[:nb + 1])
+    d_sc = torch.from_numpy(sc).cuda()
+    d_lz = torch.zeros((N,), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.crf_logz_dev(d_sc.data_ptr(), T, N, with_blank, d_lz.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(d_lz.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # linearity property of the partition function: adding a constant c to every score adds T * c
+    got2 = ctx.crf_logz(sc + np.float32(0.25)) if with_blank else None
+    if got2 is not None:
+        assert np.allclose(got2, ref + 0.25 * T, rtol=0, atol=2e-3 * max(T, 1) ** 0.5 + 1e-4)
+    with pytest.raises(ValueError):
+        ctx.crf_logz(sc[:, :, :-1])
+    ctx.close()
+
+
+def test_model_logz_and_normalise():
+    from conftest import make_config
+    from xna_basecaller_amd.crf import Model
+    model = Model(make_config(32, "NACGTXY")).to("cuda")
+    sc = random_scores(120, 4, 6, seed=5, with_blank=True)
+    lz = model.logZ(sc)
+    ref = oracle.decode(sc, 6, 3, want=("logz",))["logz"]
+    assert np.array_equal(lz, ref)
+    nrm = model.normalise(sc)
+    assert nrm.shape == sc.shape and np.allclose(model.logZ(nrm), 0.0, atol=2e-3)

@@ -18,7 +18,7 @@ XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8, XB_PREC_F16F8_IN1 = 0, 1, 2, 3
 
 EXPORTS = [
     "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",
-    "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev",
+    "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev", "xb_crf_logz", "xb_crf_logz_dev",
     "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
     "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
     "xb_submit_chunks", "xb_collect_chunks",
@@ -68,6 +68,8 @@ def load():
     lib.xb_encode_dev.argtypes = [vp, vp, ip, ip, vp]
     lib.xb_decode.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, vp, vp, vp]
     lib.xb_decode_dev.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, vp, vp, vp]
+    lib.xb_crf_logz.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.xb_crf_logz_dev.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
@@ -162,6 +164,22 @@ class Context:
         self._check(self.lib.xb_decode(self.h, scores.ctypes.data, T, n, int(bool(has_blank)),
                                        "".join(alphabet).encode(), _ptr(labels), seq.ctypes.data, lens.ctypes.data))
         return (seq, lens, labels) if want_labels else (seq, lens)
+
+    def crf_logz(self, scores, has_blank=None):
+        """(T, n, C) scores -> (n,) fp32 log partition function (CTC_CRF.logZ, crf/model.py:41-46)."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, n, Cin = scores.shape
+        if has_blank is None:
+            has_blank = Cin == self.C_blank
+        if Cin != (self.C_blank if has_blank else self.C_noblank):
+            raise ValueError("scores last dim %d does not match the model (%d with blanks, %d without)"
+                             % (Cin, self.C_blank, self.C_noblank))
+        logz = np.empty((n,), dtype=np.float32)
+        self._check(self.lib.xb_crf_logz(self.h, scores.ctypes.data, T, n, int(bool(has_blank)), logz.ctypes.data))
+        return logz
+
+    def crf_logz_dev(self, d_scores, T, n, has_blank, d_logz):
+        self._check(self.lib.xb_crf_logz_dev(self.h, _ptr(d_scores), T, n, int(bool(has_blank)), _ptr(d_logz)))
 
     def basecall_chunks(self, signal, alphabet):
         signal = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1, self.chunk_len)

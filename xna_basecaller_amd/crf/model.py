@@ -261,6 +261,21 @@ class Model(torch.nn.Module):
     def decode(self, x):
         return self.decode_batch(np.asarray(x)[:, None, :])[0]
 
+    def logZ(self, scores):
+        """(T,N,C) scores -> (N,) log partition function (CTC_CRF.logZ, crf/model.py:41-46), on the device."""
+        if hasattr(scores, "detach"):
+            scores = scores.detach().to(torch.float32).cpu().numpy()
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, N, _ = scores.shape
+        return self.context(T * self.stride, N).crf_logz(scores)
+
+    def normalise(self, scores):
+        """scores - logZ / T (CTC_CRF.normalise, crf/model.py:48-49)."""
+        if hasattr(scores, "detach"):
+            scores = scores.detach().to(torch.float32).cpu().numpy()
+        scores = np.asarray(scores, dtype=np.float32)
+        return scores - (self.logZ(scores) / np.float32(len(scores)))[None, :, None]
+
     def basecall_chunks(self, batch):
         """Fused encode + decode of a (N,1,L) batch -> (seq (N,T) int8 left-packed ASCII, lens (N,))."""
         sig = self._as_signal(batch)

@@ -453,7 +453,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
 }
 
 int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, int ld, const char *alphabet,
-               int8_t *d_labels, int8_t *d_seq, int32_t *d_len, hipStream_t st = nullptr)
+               int8_t *d_labels, int8_t *d_seq, int32_t *d_len, hipStream_t st = nullptr, float *d_logz = nullptr)
 {
     if (!st) st = ctx->stream;
     const xb_config &c = ctx->cfg;
@@ -462,7 +462,8 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
     p.scores = d_scores; p.T = T; p.N = n; p.S = ctx->S; p.hi = ctx->hi; p.nb = c.n_base;
     p.cin = has_blank ? ctx->S * (c.n_base + 1) : ctx->S * c.n_base;
     p.ld = ld; p.has_blank = has_blank; p.blank = c.blank_score;
-    p.alpha = ctx->alpha; p.beta = ctx->beta; p.bmax = ctx->bmax; p.logz = nullptr;
+    p.alpha = ctx->alpha; p.beta = ctx->beta; p.bmax = ctx->bmax;
+    p.logz = d_logz; p.logz_only = d_logz && !d_labels && !d_seq && !d_len;
     p.qbuf = ctx->qbuf; p.ldq = (ctx->S * (c.n_base + 1) + 3) & ~3;
     p.labels = d_labels; p.seq = d_seq; p.seq_len = d_len;
     memset(p.alphabet, 0, sizeof p.alphabet);
@@ -787,6 +788,35 @@ XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_bla
     if (labels) XB_HIP(ctx, hipMemcpyAsync(labels, ctx->labels, (size_t)n * T, hipMemcpyDeviceToHost, ctx->stream));
     if (seq) XB_HIP(ctx, hipMemcpyAsync(seq, ctx->seq, (size_t)n * T, hipMemcpyDeviceToHost, ctx->stream));
     if (seq_len) XB_HIP(ctx, hipMemcpyAsync(seq_len, ctx->seq_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!d_scores || !d_logz) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = join_async_decode(ctx)) return rc;
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, d_logz);
+}
+
+XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!scores || !logz) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcj = join_async_decode(ctx)) return rcj;
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
+    // the (N) result goes through the head of the bmax workspace: the Log forward sweep does not touch it
+    float *d_logz = ctx->bmax;
+    int rc = run_decode(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, d_logz);
+    if (rc) return rc;
+    XB_HIP(ctx, hipMemcpyAsync(logz, d_logz, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return xb_synchronize(ctx);
 }
 

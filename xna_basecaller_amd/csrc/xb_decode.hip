@@ -501,6 +501,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
     const float logZ = sBc[1];
+    if (p.logz_only) return;            // partition function only (uniform)
 #ifdef XB_LSTM_STAMPS
     if (p.debug_stop == 1) return;   // diagnostic build only: time sweep 1 alone
 #endif

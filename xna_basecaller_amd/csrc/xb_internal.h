@@ -17,6 +17,7 @@ struct DecodeParams {
     float *qbuf;                  // (T, N, ldq) fp32 log-posteriors written by sweep 2, read by sweep 3
     int ldq;                      // >= S*(nb+1), multiple of 4
     float *logz;                  // (N) or nullptr
+    int logz_only;                // 1: stop after the Log forward sweep (xb_crf_logz)
     int8_t *labels;               // (N, T) or nullptr
     int8_t *seq;                  // (N, T) or nullptr
     int32_t *seq_len;             // (N) or nullptr
