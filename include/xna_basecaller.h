@@ -128,11 +128,21 @@ XB_API int xb_decode_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int h
                          const char *alphabet, int8_t *d_labels, int8_t *d_seq, int32_t *d_seq_len);
 
 /*
- * CTC_CRF.logZ (crf/model.py:41-46; seqdist sparse.logZ with the Log semiring): the partition function of every chunk,
- * logZ[n] = logsumexp_j alpha_T[j] of the forward recursion alpha_0 = 0, alpha_{t+1}[j] = logsumexp_k(M[t,j,k] +
- * alpha_t[idx[j,k]]) -- the first sweep of the decode, on its own.  scores as for xb_decode; logz (n) fp32.
- * (`normalise(scores)` of crf/model.py:48-49 is scores - logZ[:, None] / T on the caller's side.)
+ * The Log-semiring scans of the CRF on their own (seqdist `sparse` operators behind crf/model.py:41-61): any of
+ *   alpha (T+1, n, S)  CTC_CRF.forward_scores  (crf/model.py:50-54): alpha_0 = 0, alpha_{t+1}[j] = LSE_k(M[t,j,k] + alpha_t[idx[j,k]])
+ *   beta  (T+1, n, S)  CTC_CRF.backward_scores (crf/model.py:56-60): beta_T = 0, beta_t[i] = LSE over edges (j,k) leaving i of
+ *                      (M[t,j,k] + beta_{t+1}[j])
+ *   logz  (n)          CTC_CRF.logZ            (crf/model.py:41-46): LSE_j alpha_T[j]   (`normalise` = scores - logz / T)
+ *   post  (T, n, S*(n_base+1))  the edge posteriors exp(alpha_t[src] + M + beta_{t+1}[dst] - logZ) = d logZ / d scores
+ *                      (seqdist `posteriors`, Log semiring; the blank column is part of the layout also when the scores
+ *                      come without it); the _dev variant writes rows of stride (S*(n_base+1) + 3) & ~3 floats.
+ * NULL outputs are skipped (alpha/logz alone stop after the forward sweep).  Same arithmetic contract as the decode:
+ * bit-equal to the oracle.  xb_crf_logz = xb_crf_scans with only logz.
  */
+XB_API int xb_crf_scans(xb_ctx *ctx, const float *scores, int T, int n, int has_blank,
+                        float *alpha, float *beta, float *logz, float *post);
+XB_API int xb_crf_scans_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank,
+                            float *d_alpha, float *d_beta, float *d_logz, float *d_post);
 XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz);
 XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz);
 

@@ -204,3 +204,55 @@ def test_model_logz_and_normalise():
     assert np.array_equal(lz, ref)
     nrm = model.normalise(sc)
     assert nrm.shape == sc.shape and np.allclose(model.logZ(nrm), 0.0, atol=2e-3)
+
+
+@pytest.mark.parametrize("nb,with_blank,T,N", [(4, True, 50, 3), (5, True, 333, 4), (5, False, 64, 2), (6, True, 700, 5),
+                                               (6, False, 2000, 3)])
+def test_crf_scans_are_the_oracles_bit_for_bit(nb, with_blank, T, N):
+    """xb_crf_scans: forward / backward scores, logZ and the edge posteriors (CTC_CRF.forward_scores / backward_scores /
+    logZ, seqdist posteriors; crf/model.py:41-61) -- every output has the oracle's bits, in every combination of
+    requested outputs, and a decode afterwards still gives the oracle's labels (shared workspaces)."""
+    import torch
+    ctx = _ctx(nb, T, N)
+    S, E = nb ** 3, nb + 1
+    sc = random_scores(T, N, nb, seed=7 * nb + T, with_blank=with_blank)
+    ref = oracle.decode(sc, nb, 3, blank_score=None if with_blank else 2.0, want=("alpha", "beta", "logz", "post"))
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for want in (("alpha", "beta", "logz", "post"), ("post",), ("beta",), ("alpha", "logz"), ("logz", "post")):
+        got = ctx.crf_scans(sc, want=want)
+        for k in want:
+            assert got[k].shape == ref[k].shape, k
+            assert np.array_equal(bits(got[k]), bits(ref[k])), (want, k, np.abs(got[k] - ref[k]).max())
+    # posteriors of a step sum to one
+    post = ctx.crf_scans(sc, want=("post",))["post"]
+    # (fp32 log domain: the exponent alpha + M + beta - logZ carries the rounding of numbers of size |logZ|)
+    assert np.abs(post.reshape(T, N, -1).sum(-1) - 1.0).max() < 4e-6 * max(1.0, float(np.abs(ref["logz"]).max()))
+    # device-pointer variant (padded posterior rows)
+    ldq = (S * E + 3) & ~3
+    d_sc = torch.from_numpy(sc).cuda()
+    d_a = torch.zeros((T + 1, N, S), dtype=torch.float32, device="cuda")
+    d_b = torch.zeros((T + 1, N, S), dtype=torch.float32, device="cuda")
+    d_lz = torch.zeros((N,), dtype=torch.float32, device="cuda")
+    d_p = torch.zeros((T, N, ldq), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.crf_scans_dev(d_sc.data_ptr(), T, N, with_blank, d_a.data_ptr(), d_b.data_ptr(), d_lz.data_ptr(), d_p.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(bits(d_a.cpu().numpy()), bits(ref["alpha"]))
+    assert np.array_equal(bits(d_b.cpu().numpy()), bits(ref["beta"]))
+    assert np.array_equal(bits(d_lz.cpu().numpy()), bits(ref["logz"]))
+    assert np.array_equal(bits(d_p.cpu().numpy()[:, :, :S * E]), bits(ref["post"]))
+    _check(ctx, sc, nb, "NACGTXY"[:nb + 1], blank=None if with_blank else 2.0)
+    with pytest.raises(_lib.XbError):
+        ctx.crf_scans(sc, want=())
+    ctx.close()
+
+
+def test_model_scan_operators():
+    from conftest import make_config
+    from xna_basecaller_amd.crf import Model
+    model = Model(make_config(32, "NACGTX")).to("cuda")
+    sc = random_scores(90, 3, 5, seed=8, with_blank=True)
+    ref = oracle.decode(sc, 5, 3, want=("alpha", "beta", "post"))
+    assert np.array_equal(model.forward_scores(sc), ref["alpha"])
+    assert np.array_equal(model.backward_scores(sc), ref["beta"])
+    assert np.array_equal(model.posteriors(sc), ref["post"])

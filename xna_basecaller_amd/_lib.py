@@ -18,7 +18,7 @@ XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8, XB_PREC_F16F8_IN1 = 0, 1, 2, 3
 
 EXPORTS = [
     "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",
-    "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev", "xb_crf_logz", "xb_crf_logz_dev",
+    "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev", "xb_crf_logz", "xb_crf_logz_dev", "xb_crf_scans", "xb_crf_scans_dev",
     "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
     "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
     "xb_submit_chunks", "xb_collect_chunks",
@@ -70,6 +70,8 @@ def load():
     lib.xb_decode_dev.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, vp, vp, vp]
     lib.xb_crf_logz.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.xb_crf_logz_dev.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.xb_crf_scans.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp, vp]
+    lib.xb_crf_scans_dev.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp, vp]
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
@@ -177,6 +179,27 @@ class Context:
         logz = np.empty((n,), dtype=np.float32)
         self._check(self.lib.xb_crf_logz(self.h, scores.ctypes.data, T, n, int(bool(has_blank)), logz.ctypes.data))
         return logz
+
+    def crf_scans(self, scores, want=("alpha", "beta", "logz", "post"), has_blank=None):
+        """(T, n, C) scores -> dict of the Log scans (xb_crf_scans): 'alpha', 'beta' (T+1, n, S), 'logz' (n,),
+        'post' (T, n, S*(n_base+1))."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, n, Cin = scores.shape
+        if has_blank is None:
+            has_blank = Cin == self.C_blank
+        if Cin != (self.C_blank if has_blank else self.C_noblank):
+            raise ValueError("scores last dim %d does not match the model (%d with blanks, %d without)"
+                             % (Cin, self.C_blank, self.C_noblank))
+        S = self.C_blank // (self.n_base + 1)
+        shapes = {"alpha": (T + 1, n, S), "beta": (T + 1, n, S), "logz": (n,), "post": (T, n, self.C_blank)}
+        out = {k: np.empty(shapes[k], dtype=np.float32) for k in want}
+        self._check(self.lib.xb_crf_scans(self.h, scores.ctypes.data, T, n, int(bool(has_blank)), _ptr(out.get("alpha")),
+                                          _ptr(out.get("beta")), _ptr(out.get("logz")), _ptr(out.get("post"))))
+        return out
+
+    def crf_scans_dev(self, d_scores, T, n, has_blank, d_alpha=None, d_beta=None, d_logz=None, d_post=None):
+        self._check(self.lib.xb_crf_scans_dev(self.h, _ptr(d_scores), T, n, int(bool(has_blank)), _ptr(d_alpha), _ptr(d_beta),
+                                              _ptr(d_logz), _ptr(d_post)))
 
     def crf_logz_dev(self, d_scores, T, n, has_blank, d_logz):
         self._check(self.lib.xb_crf_logz_dev(self.h, _ptr(d_scores), T, n, int(bool(has_blank)), _ptr(d_logz)))

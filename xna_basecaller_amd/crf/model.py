@@ -269,6 +269,25 @@ class Model(torch.nn.Module):
         T, N, _ = scores.shape
         return self.context(T * self.stride, N).crf_logz(scores)
 
+    def _scans(self, scores, want):
+        if hasattr(scores, "detach"):
+            scores = scores.detach().to(torch.float32).cpu().numpy()
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, N, _ = scores.shape
+        return self.context(T * self.stride, N).crf_scans(scores, want=want)
+
+    def forward_scores(self, scores):
+        """(T,N,C) -> (T+1,N,S) Log forward scores (CTC_CRF.forward_scores, crf/model.py:50-54)."""
+        return self._scans(scores, ("alpha",))["alpha"]
+
+    def backward_scores(self, scores):
+        """(T,N,C) -> (T+1,N,S) Log backward scores (CTC_CRF.backward_scores, crf/model.py:56-60)."""
+        return self._scans(scores, ("beta",))["beta"]
+
+    def posteriors(self, scores):
+        """(T,N,C) -> (T,N,S*(n_base+1)) edge posteriors = d logZ / d scores (seqdist `posteriors`, Log semiring)."""
+        return self._scans(scores, ("post",))["post"]
+
     def normalise(self, scores):
         """scores - logZ / T (CTC_CRF.normalise, crf/model.py:48-49)."""
         if hasattr(scores, "detach"):

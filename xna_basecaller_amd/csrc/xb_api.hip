@@ -77,7 +77,7 @@ struct xb_ctx {
     half_t *x_hi[2] = {}, *x_lo[2] = {};
     float *gin = nullptr, *gin2 = nullptr, *c_state = nullptr, *scores = nullptr, *scores2 = nullptr;
     half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
-    float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr;
+    float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr, *logz = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
     int32_t *seq_len = nullptr;
     unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
@@ -452,8 +452,13 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
     return XB_OK;
 }
 
+// optional outputs of the Log scans (xb_crf_logz / xb_crf_scans)
+struct ScanOut {
+    float *alpha = nullptr, *beta = nullptr, *logz = nullptr, *post = nullptr;   // device; post has row stride ldq
+};
+
 int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, int ld, const char *alphabet,
-               int8_t *d_labels, int8_t *d_seq, int32_t *d_len, hipStream_t st = nullptr, float *d_logz = nullptr)
+               int8_t *d_labels, int8_t *d_seq, int32_t *d_len, hipStream_t st = nullptr, const ScanOut *scan = nullptr)
 {
     if (!st) st = ctx->stream;
     const xb_config &c = ctx->cfg;
@@ -463,8 +468,14 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
     p.cin = has_blank ? ctx->S * (c.n_base + 1) : ctx->S * c.n_base;
     p.ld = ld; p.has_blank = has_blank; p.blank = c.blank_score;
     p.alpha = ctx->alpha; p.beta = ctx->beta; p.bmax = ctx->bmax;
-    p.logz = d_logz; p.logz_only = d_logz && !d_labels && !d_seq && !d_len;
     p.qbuf = ctx->qbuf; p.ldq = (ctx->S * (c.n_base + 1) + 3) & ~3;
+    if (scan) {
+        if (scan->alpha) p.alpha = scan->alpha;
+        p.logz = scan->logz;
+        p.beta_out = scan->beta;
+        if (scan->post) { p.qbuf = scan->post; p.post_mode = 1; }
+        p.stop_after = (scan->beta || scan->post) ? 2 : 1;
+    }
     p.labels = d_labels; p.seq = d_seq; p.seq_len = d_len;
     memset(p.alphabet, 0, sizeof p.alphabet);
     if (alphabet) {
@@ -603,6 +614,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->logz, N);
     rc = rc ? rc : dev_alloc(ctx, &ctx->qbuf, T * N * ((Cb + 3) & ~(size_t)3));
     rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
@@ -791,33 +803,60 @@ XB_API int xb_decode(xb_ctx *ctx, const float *scores, int T, int n, int has_bla
     return xb_synchronize(ctx);
 }
 
-XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz)
+XB_API int xb_crf_scans_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_alpha, float *d_beta,
+                            float *d_logz, float *d_post)
 {
     if (!ctx) return XB_ERR_INVALID;
     if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
-    if (!d_scores || !d_logz) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    if (!d_scores) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    if (!d_alpha && !d_beta && !d_logz && !d_post) return fail(ctx, XB_ERR_INVALID, "no output requested");
     XB_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = join_async_decode(ctx)) return rc;
     const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
-    return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, d_logz);
+    ScanOut so;
+    so.alpha = d_alpha; so.beta = d_beta; so.logz = d_logz; so.post = d_post;
+    return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, &so);
+}
+
+XB_API int xb_crf_scans(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *alpha, float *beta, float *logz,
+                        float *post)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!scores) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    if (!alpha && !beta && !logz && !post) return fail(ctx, XB_ERR_INVALID, "no output requested");
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcj = join_async_decode(ctx)) return rcj;
+    const int S = ctx->S, E = ctx->cfg.n_base + 1;
+    const int ld = has_blank ? S * E : ctx->O;
+    XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
+    // device staging in the decode's own workspaces: alpha -> its stash, beta -> the (otherwise unused) beta stash, P -> the
+    // Q buffer (row stride ldq), logZ -> its own (max_batch) buffer
+    const int ldq = (S * E + 3) & ~3;
+    ScanOut so;
+    so.alpha = ctx->alpha; so.beta = beta ? ctx->beta : nullptr; so.post = post ? ctx->qbuf : nullptr;
+    so.logz = logz ? ctx->logz : nullptr;
+    int rc = run_decode(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, &so);
+    if (rc) return rc;
+    const size_t sv = sizeof(float) * (size_t)(T + 1) * n * S;
+    if (alpha) XB_HIP(ctx, hipMemcpyAsync(alpha, ctx->alpha, sv, hipMemcpyDeviceToHost, ctx->stream));
+    if (beta) XB_HIP(ctx, hipMemcpyAsync(beta, ctx->beta, sv, hipMemcpyDeviceToHost, ctx->stream));
+    if (logz) XB_HIP(ctx, hipMemcpyAsync(logz, so.logz, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (post)
+        XB_HIP(ctx, hipMemcpy2DAsync(post, sizeof(float) * (size_t)S * E, ctx->qbuf, sizeof(float) * (size_t)ldq,
+                                     sizeof(float) * (size_t)S * E, (size_t)T * n, hipMemcpyDeviceToHost, ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz)
+{
+    return xb_crf_scans_dev(ctx, d_scores, T, n, has_blank, nullptr, nullptr, d_logz, nullptr);
 }
 
 XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz)
 {
-    if (!ctx) return XB_ERR_INVALID;
-    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
-    if (!scores || !logz) return fail(ctx, XB_ERR_INVALID, "null host pointer");
-    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
-    XB_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rcj = join_async_decode(ctx)) return rcj;
-    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
-    XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
-    // the (N) result goes through the head of the bmax workspace: the Log forward sweep does not touch it
-    float *d_logz = ctx->bmax;
-    int rc = run_decode(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, d_logz);
-    if (rc) return rc;
-    XB_HIP(ctx, hipMemcpyAsync(logz, d_logz, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    return xb_synchronize(ctx);
+    return xb_crf_scans(ctx, scores, T, n, has_blank, nullptr, nullptr, logz, nullptr);
 }
 
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet, int8_t *d_seq,

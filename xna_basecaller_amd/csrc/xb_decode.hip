@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
     const float logZ = sBc[1];
-    if (p.logz_only) return;            // partition function only (uniform)
+    if (p.stop_after == 1) return;      // forward scores / partition function only (uniform)
 #ifdef XB_LSTM_STAMPS
     if (p.debug_stop == 1) return;   // diagnostic build only: time sweep 1 alone
 #endif
@@ -513,10 +513,13 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         const int i = (stc % NB) * hi + stc / NB;
         const int kk = stc % NB + 1;                               // = i / hi + 1: column of the new-base edges
         const int jb = (stc / NB) * NB;                            // = (i % hi) * NB: first destination
+        float *beta_out = p.beta_out ? p.beta_out + (size_t)n * S : nullptr;     // uniform
+        const bool post_mode = p.post_mode != 0;
         if (tid < S) {
             sA[(T & 1) * S + tid] = 0.0f;
             sX[(T & 1) * S + tid] = 0.0f;
             bmax[(size_t)T * sstride + tid] = 0.0f;
+            if (beta_out) beta_out[(size_t)T * sstride + tid] = 0.0f;
         }
         // per-lane constants of local edge r: destination state and staged-row index of its score
         // (e = 0: stay, j = i, column 0; e >= 1: j = jb + e - 1, column kk)
@@ -609,11 +612,17 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                         mm = maxf(mm, lo[r] + mjv[r]);
                     }
                 }
+                if (post_mode) {                                 // uniform: the row carries P itself (xb_crf_scans)
+#pragma unroll
+                    for (int r = 0; r < EPER; ++r)
+                        if (r < kcnt && act) qs[dstj[r] * E + ((r == 0 && stay0) ? 0 : kk)] = P[r];
+                }
                 if (LPS == 2) mm = pair_max(mm);
                 if (ph == 0 && act) {
                     sA[(t & 1) * S + i] = bv;
                     sX[(t & 1) * S + i] = mm;
                     bmax[(size_t)t * sstride + i] = mm;
+                    if (beta_out) beta_out[(size_t)t * sstride + i] = bv;
                 }
             }
           }
@@ -623,6 +632,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
 
+    if (p.stop_after == 2) return;      // scans only (uniform)
 #ifdef XB_LSTM_STAMPS
     if (p.debug_stop == 2) return;   // diagnostic build only: sweeps 1+2
 #endif

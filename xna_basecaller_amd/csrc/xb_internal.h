@@ -17,7 +17,10 @@ struct DecodeParams {
     float *qbuf;                  // (T, N, ldq) fp32 log-posteriors written by sweep 2, read by sweep 3
     int ldq;                      // >= S*(nb+1), multiple of 4
     float *logz;                  // (N) or nullptr
-    int logz_only;                // 1: stop after the Log forward sweep (xb_crf_logz)
+    int stop_after;               // 0: full decode; 1: return after the Log forward sweep (alpha, logZ); 2: after the Log
+                                  // backward sweep (xb_crf_scans)
+    float *beta_out;              // (T+1, N, S) or nullptr: the Log backward scores, written by sweep 2
+    int post_mode;                // 1: sweep 2 writes the posteriors P instead of Q = log(P + 1e-8) into qbuf
     int8_t *labels;               // (N, T) or nullptr
     int8_t *seq;                  // (N, T) or nullptr
     int32_t *seq_len;             // (N) or nullptr
