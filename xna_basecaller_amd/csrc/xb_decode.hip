@@ -348,7 +348,9 @@ struct Edges {
 
 // NB bases, BS threads (multiple of 64, >= LPS * S), HB: the scores carry the blank column, LPS lanes per state,
 // VW: 4 = 16-byte staging loads in sweep 2 (row stride and base 16-byte aligned), 1 = 4-byte loads
-template <int NB, int BS, bool HB, int LPS, int VW>
+// SCAN = true: the xb_crf_scans variant (optional beta / posterior outputs, early return after sweep 1 or 2); the decode
+// proper is compiled without those paths (measured: 1-2 % of the decode time when they are run-time branches).
+template <int NB, int BS, bool HB, int LPS, int VW, bool SCAN>
 __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 {
     constexpr int E = NB + 1;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
     const float logZ = sBc[1];
-    if (p.stop_after == 1) return;      // forward scores / partition function only (uniform)
+    if (SCAN && p.stop_after == 1) return;      // forward scores / partition function only (uniform)
 #ifdef XB_LSTM_STAMPS
     if (p.debug_stop == 1) return;   // diagnostic build only: time sweep 1 alone
 #endif
@@ -513,8 +515,8 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         const int i = (stc % NB) * hi + stc / NB;
         const int kk = stc % NB + 1;                               // = i / hi + 1: column of the new-base edges
         const int jb = (stc / NB) * NB;                            // = (i % hi) * NB: first destination
-        float *beta_out = p.beta_out ? p.beta_out + (size_t)n * S : nullptr;     // uniform
-        const bool post_mode = p.post_mode != 0;
+        float *beta_out = SCAN && p.beta_out ? p.beta_out + (size_t)n * S : nullptr;     // uniform
+        const bool post_mode = SCAN && p.post_mode != 0;
         if (tid < S) {
             sA[(T & 1) * S + tid] = 0.0f;
             sX[(T & 1) * S + tid] = 0.0f;
@@ -597,6 +599,11 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 } else {
                     sm = pair_sum_ordered<E>(ex);
                 }
+                if (post_mode) {                                 // uniform, xb_crf_scans: the row carries P itself (stored here,
+#pragma unroll                                                   // so that P is dead before the logs in the decode proper)
+                    for (int r = 0; r < EPER; ++r)
+                        if (r < kcnt && act) qs[dstj[r] * E + ((r == 0 && stay0) ? 0 : kk)] = P[r];
+                }
                 // the EPER logs of Q = log(P + 1e-8) and the log of the logsumexp, two at a time
                 float la[EPER + 1], lo[EPER + 1];
 #pragma unroll
@@ -608,14 +615,9 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 for (int r = 0; r < EPER; ++r) {
                     if (r < kcnt) {
                         const int k = (r == 0 && stay0) ? 0 : kk;
-                        if (act) qs[dstj[r] * E + k] = lo[r];
+                        if (act && !post_mode) qs[dstj[r] * E + k] = lo[r];
                         mm = maxf(mm, lo[r] + mjv[r]);
                     }
-                }
-                if (post_mode) {                                 // uniform: the row carries P itself (xb_crf_scans)
-#pragma unroll
-                    for (int r = 0; r < EPER; ++r)
-                        if (r < kcnt && act) qs[dstj[r] * E + ((r == 0 && stay0) ? 0 : kk)] = P[r];
                 }
                 if (LPS == 2) mm = pair_max(mm);
                 if (ph == 0 && act) {
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         __syncthreads();
     }
 
-    if (p.stop_after == 2) return;      // scans only (uniform)
+    if (SCAN && p.stop_after == 2) return;      // scans only (uniform)
 #ifdef XB_LSTM_STAMPS
     if (p.debug_stop == 2) return;   // diagnostic build only: sweeps 1+2
 #endif
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
     }
 }
 
-template <int NB, int BS, int LPS>
+template <int NB, int BS, int LPS, bool SCAN>
 hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
     // must mirror the kernel's LDS carve
@@ -791,9 +793,9 @@ hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
     dim3 grid(p.N), block(BS);
 #define XB_LAUNCH(HB, VW)                                                                                          \
     do {                                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_decode_kernel<NB, BS, HB, LPS, VW>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crf_decode_kernel<NB, BS, HB, LPS, VW, SCAN>),         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        hipLaunchKernelGGL((crf_decode_kernel<NB, BS, HB, LPS, VW>), grid, block, lds, stream, p);                 \
+        hipLaunchKernelGGL((crf_decode_kernel<NB, BS, HB, LPS, VW, SCAN>), grid, block, lds, stream, p);                 \
     } while (0)
     if (p.has_blank) {
         if (vw == 4) XB_LAUNCH(true, 4); else XB_LAUNCH(true, 1);
@@ -805,19 +807,19 @@ hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
 }
 
 // Block = smallest multiple of 64 threads (from a short list, pruned per alphabet) that holds LPS lanes for each state.
-template <int NB, int LPS>
+template <int NB, int LPS, bool SCAN>
 hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
     const int need = LPS * p.S;
-    if (need <= 64) return launch_nb_bs<NB, 64, LPS>(p, vw, stream);
-    if (need <= 128) return launch_nb_bs<NB, 128, LPS>(p, vw, stream);
-    if (need <= 256) return launch_nb_bs<NB, 256, LPS>(p, vw, stream);
+    if (need <= 64) return launch_nb_bs<NB, 64, LPS, SCAN>(p, vw, stream);
+    if (need <= 128) return launch_nb_bs<NB, 128, LPS, SCAN>(p, vw, stream);
+    if (need <= 256) return launch_nb_bs<NB, 256, LPS, SCAN>(p, vw, stream);
     if constexpr (NB == 6) {
-        if (need <= 448) return launch_nb_bs<NB, 448, LPS>(p, vw, stream);     // 2 x 216 states
+        if (need <= 448) return launch_nb_bs<NB, 448, LPS, SCAN>(p, vw, stream);     // 2 x 216 states
     } else {
-        if (need <= 640) return launch_nb_bs<NB, 640, LPS>(p, vw, stream);     // 5^4 states / 2 x 4^4
+        if (need <= 640) return launch_nb_bs<NB, 640, LPS, SCAN>(p, vw, stream);     // 5^4 states / 2 x 4^4
         if constexpr (NB == 4 && LPS == 1) {
-            if (need <= 1024) return launch_nb_bs<NB, 1024, LPS>(p, vw, stream);   // 4^5 states
+            if (need <= 1024) return launch_nb_bs<NB, 1024, LPS, SCAN>(p, vw, stream);   // 4^5 states
         }
     }
     return hipErrorInvalidValue;
@@ -825,8 +827,10 @@ hipError_t launch_nb_lps(const xb::DecodeParams &p, int vw, hipStream_t stream)
 template <int NB>
 hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
 {
-    if (xb::decode_lanes_per_state(p.S, p.N) == 2) return launch_nb_lps<NB, 2>(p, vw, stream);
-    return launch_nb_lps<NB, 1>(p, vw, stream);
+    // the scan variant exists with one lane per state only (the results do not depend on the lane split)
+    if (p.stop_after || p.beta_out || p.post_mode) return launch_nb_lps<NB, 1, true>(p, vw, stream);
+    if (xb::decode_lanes_per_state(p.S, p.N) == 2) return launch_nb_lps<NB, 2, false>(p, vw, stream);
+    return launch_nb_lps<NB, 1, false>(p, vw, stream);
 }
 
 }  // namespace
