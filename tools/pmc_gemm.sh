@@ -18,11 +18,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
   timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-chunks 0 $BENCH_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
+        k = re.sub(r"^(void )?\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
     for k, d in agg.items():
