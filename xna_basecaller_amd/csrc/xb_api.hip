@@ -85,6 +85,7 @@ struct xb_ctx {
     int lstm_mode = 0;
     int lstm_resident = -1;      // workgroups of the persistent kernel admitted per CU (occupancy query, lazily)
     int lstm_dual_resident = -1; // the same for the two-groups-per-workgroup variant (larger LDS footprint)
+    int in1_layers = 31;         // XB_IN1_LAYERS (diagnostic): layers whose input projection XB_PREC_F16F8_IN1 reduces
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
     bool profiling = false;
@@ -293,7 +294,9 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     if (ng.layer < 5) {
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
-        if (ctx->cfg.precision == XB_PREC_F16F8_IN1) g.nsplit = 1;               // main product only (the q8 images stay unused)
+        // main product only (the q8 images stay unused) -- in1_layers: bit l = input projection of layer l (diagnostic
+        // XB_IN1_LAYERS, default all five)
+        if (ctx->cfg.precision == XB_PREC_F16F8_IN1 && ((ctx->in1_layers >> ng.layer) & 1)) g.nsplit = 1;
         g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
         g.gin_n = n;                                                           // member-major gin (xb_internal.h)
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, st));
@@ -562,6 +565,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     ctx->lstm_mode = cfg->lstm_mode;
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
+    if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \
