@@ -363,3 +363,33 @@ def test_column_to_set(tmp_path):
     assert util.column_to_set(str(f), skip_header=True) == {"r1", "r2", "r3"}
     assert util.column_to_set(str(f), idx=1) == {"x", "5", "6", "7"}
     assert util.column_to_set(str(tmp_path / "absent")) is None and util.column_to_set(None) is None
+
+
+def test_compute_transition_probs_layout():
+    """CTC_CRF.compute_transition_probs (crf/model.py:62-76): from the (new_state, dropped_base) edge layout to
+    (old_state, emitted_base), softmax over a source state's nb + 1 options -- checked edge by edge with plain loops."""
+    from xna_basecaller_amd.crf.model import CTC_CRF
+    nb, sl = 4, 3
+    crf = CTC_CRF(sl, "NACGT")
+    S, hi = nb ** sl, nb ** (sl - 1)
+    rng = np.random.default_rng(4)
+    T, N = 3, 2
+    scores = rng.standard_normal((T, N, S * (nb + 1))).astype(np.float32)
+    betas = rng.standard_normal((T + 1, N, S)).astype(np.float32)
+    tp, ip = crf.compute_transition_probs(scores, betas)
+    assert tp.shape == (T, N, S, nb + 1) and ip.shape == (N, S)
+    M = scores.reshape(T, N, S, nb + 1)
+    idx = crf.idx.numpy()
+    for t in range(T):
+        for n in range(N):
+            for src in range(0, S, 7):
+                w = np.empty(nb + 1)
+                w[0] = M[t, n, src, 0] + betas[t + 1, n, src]                      # stay
+                for b in range(nb):                                                  # emit base b: destination j
+                    j, k = (src % hi) * nb + b, src // hi + 1
+                    assert idx[j, k] == src
+                    w[1 + b] = M[t, n, j, k] + betas[t + 1, n, j]
+                w = np.exp(w - w.max())
+                assert np.allclose(tp[t, n, src], w / w.sum(), atol=1e-6)
+    e = np.exp(betas[0] - betas[0].max(-1, keepdims=True))
+    assert np.allclose(ip, e / e.sum(-1, keepdims=True), atol=1e-6)

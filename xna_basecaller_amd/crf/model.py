@@ -39,6 +39,29 @@ class CTC_CRF:
         path = np.asarray(path)
         return alphabet[path[path != 0]].tobytes().decode()
 
+    def compute_transition_probs(self, scores, betas):
+        """
+        (T,N,C) scores with the blank column and (T+1,N,S) Log backward scores -> (trans_probs (T,N,S,nb+1),
+        init_state_probs (N,S)): per source state the probabilities of staying and of emitting each base, the input of
+        the reference's beam-search branch (crf/model.py:62-76, crf/basecall.py:33-46).  Edge (j, k >= 1) of destination j
+        leaves source idx[j, k] and emits base j % nb; in the (old_state, emitted_base) layout that is
+        [src, 1 + base] with src = (k - 1) * hi + j // nb.
+        """
+        scores = np.asarray(scores, dtype=np.float32)
+        betas = np.asarray(betas, dtype=np.float32)
+        T, N, _ = scores.shape
+        nb, S = self.n_base, self.n_base ** self.state_len
+        lp = scores.reshape(T, N, S, nb + 1) + betas[1:, :, :, None]
+        moves = lp[..., 1:].transpose(0, 1, 3, 2).reshape(T, N, S, nb)       # (new_state, dropped_base) -> (old_state, emitted_base)
+        lp = np.concatenate([lp[..., :1], moves], axis=-1)
+        lp = lp - lp.max(axis=-1, keepdims=True)
+        tp = np.exp(lp)
+        tp /= tp.sum(axis=-1, keepdims=True)
+        b0 = betas[0] - betas[0].max(axis=-1, keepdims=True)
+        ip = np.exp(b0)
+        ip /= ip.sum(axis=-1, keepdims=True)
+        return tp, ip
+
     def reverse_complement(self, scores):
         """crf/model.py:78-90 on a host (T,N,C) array: flip time, complement every k-mer index."""
         scores = np.asarray(scores)
