@@ -2,6 +2,7 @@
 // reference call sites each entry point replaces).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -70,6 +71,9 @@ struct xb_ctx {
     half_t *wl_hi = nullptr, *wl_lo = nullptr;
     float *bl = nullptr;
     int w3_exp = 0, wih_exp[5] = {}, whh_exp[5] = {}, wl_exp = 0;   // q8 exponents (XB_PREC_F16F8)
+    int8_t *whh_q1[5] = {}, *whh_q0[5] = {};   // int8-limb recurrence (lstm_i8): balanced digits of W_hh, gate-interleaved rows
+    float *whh_sc[5] = {};                     // ... and the factor that turns the integer sum into the recurrent term
+    int lstm_i8 = 0;                           // XB_LSTM_I8=1 (with precision f16f8 / f16f8i): recurrence on int8 digits
 
     // activations / workspaces
     float *d_signal = nullptr;
@@ -334,8 +338,9 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
     // ... and the occupancy calculator has to admit at least one such workgroup per CU (queried once per context); a
     // context that cannot keep the persistent kernel resident falls back to one launch per time step
-    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx), 0);
-    if (ctx->lstm_dual_resident < 0) ctx->lstm_dual_resident = xb::lstm_resident_per_cu(F, precision_nsplit(ctx), 1);
+    const int rec_nsplit = (ctx->lstm_i8 && ctx->whh_q1[layer]) ? 4 : precision_nsplit(ctx);
+    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 0);
+    if (ctx->lstm_dual_resident < 0) ctx->lstm_dual_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 1);
     const bool dual_ok = ctx->lstm_dual != 0 && ctx->lstm_dual_resident >= 1;
     const int gmax = ctx->lstm_resident >= 1 ? 8 * ((ctx->cu_count / 8) / members) : 0;
     if (mode == 0) mode = gmax >= 1 ? 2 : 1;
@@ -346,6 +351,9 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state; p.xh = ctx->xh;
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
     p.sync = ctx->sync; p.error = ctx->error; p.nsplit = precision_nsplit(ctx); p.w_exp = ctx->whh_exp[layer];
+    if (ctx->lstm_i8 && ctx->whh_q1[layer]) {
+        p.nsplit = 4; p.wq1 = ctx->whh_q1[layer]; p.wq0 = ctx->whh_q0[layer]; p.wscale = ctx->whh_sc[layer];
+    }
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
     bool overlapped = false;
     if (mode == 2) {
@@ -566,6 +574,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
+    if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) != 0;
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \
@@ -719,6 +728,27 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
         split_rows(wh.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->whh_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->whh_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->whh_lo[l], lo))) return rc;
+        if (ctx->lstm_i8 && q8 && (F == 64 || F % 128 == 0)) {
+            // int8-limb image: per row q = round(W / s * 32512), s = max |W| of the row; q = 256 d1 + d0 with both digits in
+            // [-128, 127]; h is published as round(h * 32512) the same way, so W h = s / 32512^2 * sum q_w q_h
+            std::vector<int8_t> d1((size_t)4 * F * F), d0((size_t)4 * F * F);
+            std::vector<float> sc((size_t)4 * F);
+            for (int r = 0; r < 4 * F; ++r) {
+                float mx = 0.0f;
+                for (int k = 0; k < F; ++k) mx = std::max(mx, std::fabs(wh[(size_t)r * F + k]));
+                const float sr = mx > 0.0f ? mx : 1.0f;
+                sc[r] = sr / (32512.0f * 32512.0f);
+                for (int k = 0; k < F; ++k) {
+                    const int q = (int)std::lrintf(wh[(size_t)r * F + k] / sr * 32512.0f);
+                    const int lo8 = ((q + 128) & 255) - 128;
+                    d0[(size_t)r * F + k] = (int8_t)lo8;
+                    d1[(size_t)r * F + k] = (int8_t)((q - lo8) >> 8);
+                }
+            }
+            if ((rc = upload(ctx, &ctx->whh_q1[l], d1))) return rc;
+            if ((rc = upload(ctx, &ctx->whh_q0[l], d0))) return rc;
+            if ((rc = upload(ctx, &ctx->whh_sc[l], sc))) return rc;
+        }
         if ((rc = upload(ctx, &ctx->lbias[l], bb))) return rc;
     }
     split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo, q8 ? &ctx->wl_exp : nullptr);

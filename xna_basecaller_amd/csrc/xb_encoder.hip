@@ -43,6 +43,7 @@ __device__ __forceinline__ void split_f16(float v, half_t &hi, half_t &lo)
 // ---- q8 image helpers (xb_internal.h "q8 image"): OCP e4m3 bytes of hi * 2^e and of (v - hi) * 2^(e+11)
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float clamp448(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.0f), 448.0f); }
 // the conversion returns NaN (0x7f) above 448, hence the clamp wherever the magnitude is not bounded by construction
 template <bool HIGH_WORD>
@@ -607,10 +608,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     constexpr int KP = F < 128 ? F : 128;       // columns per piece
     constexpr int NP = F / KP;                  // pieces per step
     constexpr int KSP = KP / 16;                // MFMA k-steps per piece
-    constexpr int CPR = KP / 8;                 // 16-byte cells per row per piece
+    // NSPLIT == 4: the int8-limb recurrence.  h (|h| < 1) and each W_hh row (per-row scale) are 16-bit fixed point, split
+    // into two balanced signed 8-bit digits q = 256 d1 + d0; the four digit products run on v_mfma_i32_32x32x32_i8 (exact
+    // int32 sums, three accumulator sets by weight 2^16 / 2^8 / 1) and are combined in fp32 once per step.  The exchange
+    // image is one byte per element and part (part 0 = d1, part 1 = d0): half the DMA and fragment bytes of fp16 + q8.
+    constexpr bool I8 = NSPLIT == 4;
+    constexpr int ES = I8 ? 1 : 2;              // bytes per element of one exchange part
+    constexpr int CPR = KP * ES / 16;           // 16-byte cells per row per piece
     constexpr int SWZ = (CPR & -CPR) - 1;       // XOR mask that stays inside the row
-    constexpr int NPARTS = NSPLIT == 1 ? 1 : 2; // hi (, lo or, NSPLIT == 2, the q8 image)
-    constexpr int PIECE_BYTES = LG_BN * KP * 2; // one part of one piece
+    constexpr int NPARTS = NSPLIT == 1 ? 1 : 2; // hi (, lo or, NSPLIT == 2, the q8 image; NSPLIT == 4: the two digits)
+    constexpr int PIECE_BYTES = LG_BN * KP * ES; // one part of one piece
+    constexpr int STP = I8 ? 3 : NPARTS;        // staging arrays: hi pairs, lo / q8 (, NSPLIT == 4: the digit bytes)
+    static_assert(!I8 || KP == 128 || KP == 64, "int8-limb pieces are 64 or 128 columns (at least four cells per row)");
     constexpr int NG = DUAL ? 2 : 1;            // groups per workgroup
     static_assert(F % KP == 0, "feature size must be a multiple of the piece width");
 
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
     // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
     unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
-    float *sC0 = reinterpret_cast<float *>(sT + NPARTS * 16 * ST_LD);             // [NG][32 units][64 chunks] cell state
+    float *sC0 = reinterpret_cast<float *>(sT + STP * 16 * ST_LD);                // [NG][32 units][64 chunks] cell state
     // input-projection tile of the step: [NG][64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
     unsigned char *sG0 = reinterpret_cast<unsigned char *>(sC0 + NG * LG_UNITS * LG_BN);
     int *sFlag = reinterpret_cast<int *>(sG0 + NG * LG_BN * LG_UNITS * 16);
@@ -626,12 +635,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // every group-step: with all 512 registers taken hipcc otherwise parks half of it in scratch, and the reload -- a
     // scratch load with vmcnt(0) behind it -- would wait for the other group's gin tile and y stores still in flight
     unsigned char *sW0 = reinterpret_cast<unsigned char *>(sFlag) + 16 + 80;
+    float *sScale = reinterpret_cast<float *>(sW0 + 256 * 16);                  // NSPLIT == 4: row scales of the 128 gate rows
     // DUAL, even piece count: the coming group-step's first piece is requested in the DMA-free issue slots of the last piece
     constexpr bool EIL = DUAL && NP >= 2 && NP % 2 == 0;
 #ifdef XB_LSTM_STAMPS
-    constexpr bool PARK = true;         // the stamp bookkeeping costs the single-group kernel the same registers
+    constexpr bool PARK = !I8;          // the stamp bookkeeping costs the single-group kernel the same registers
 #else
-    constexpr bool PARK = DUAL;
+    constexpr bool PARK = DUAL && !I8;
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,9 +664,19 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // ---- W_hh fragments: row = gate-interleaved (unit*4+gate), lane l: row (l&31), k-chunk (l>>5)
     // NSPLIT == 2: per 32 columns one q8 fragment instead of two lo fragments -- lanes 0-31 hold the block's Wh8 half,
     // lanes 32-63 its Wl8 half (A operand of the block-scaled MFMA; the h fragments below take the opposite halves)
-    half8 wh[KS], wl[KS];
+    half8 wh[I8 ? 1 : KS], wl[I8 ? 1 : KS];
     v8i wq[KS / 2 > 0 ? KS / 2 : 1];
-    {
+    // NSPLIT == 4: per 32 columns the lane's 16 bytes of each digit of its row (k = 32 b + 16 hsel + byte)
+    v4i wd1[I8 ? KS / 2 : 1], wd0[I8 ? KS / 2 : 1];
+    if constexpr (I8) {
+        const size_t row = (size_t)ubase * 4 + (lane & 31);
+#pragma unroll
+        for (int b = 0; b < KS / 2; ++b) {
+            wd1[b] = *reinterpret_cast<const v4i *>(p.wq1 + row * F + b * 32 + hsel * 16);
+            wd0[b] = *reinterpret_cast<const v4i *>(p.wq0 + row * F + b * 32 + hsel * 16);
+        }
+        if (tid < 128) sScale[tid] = p.wscale[(size_t)mb * 128 + tid];
+    } else {
         const size_t row = (size_t)ubase * 4 + (lane & 31);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
@@ -772,7 +792,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         const int part = NPARTS == 2 ? (d & 1) : 0;
         const int q = wid + 4 * (NPARTS == 2 ? (d >> 1) : d);
         unsigned char *dst = sPiece + (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + q * 1024;
-        if (POW2) {
+        if constexpr (I8) {
+            // byte image: row stride F bytes inside a part region of XPART * 2 bytes; lane_off_step is in bytes here
+            const unsigned char *base = reinterpret_cast<const unsigned char *>(xprev) + (size_t)part * (XPART * 2) +
+                                        (size_t)(RPI * q) * F + pc * KP;                       // uniform
+            dma16_sc1(base + lane_off, dst);
+        } else if (POW2) {
             const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
             dma16_sc1(base + lane_off, dst);
         } else {
@@ -797,6 +822,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (DUAL) serve(gi);
             XB_STAMP(0);   // loop overhead / y stores of the previous group-step
             floatx16 acc[2];
+            v16i a11[I8 ? 2 : 1], amid[I8 ? 2 : 1], a00[I8 ? 2 : 1];      // NSPLIT == 4: digit-product sums by weight
             // DUAL: the group-step this workgroup serves next, whether it has a recurrent term (s > 0) and whether its
             // group has to be polled first (not in the first step of a launch: the previous launch has retired)
             const int ngi = (DUAL && gi == 0 && second) ? 1 : 0;
@@ -812,12 +838,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             int go = 0;         // EIL: request the coming group-step's first piece during the last piece
 
             if (s > 0) {
-                const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;
+                const half_t *xprev = xg + (size_t)((s - 1) & 1) * XPAR;      // (NSPLIT == 4: same byte offset, XPAR * 2)
                 {
                     int lo = lane;
                     if (PARK) asm volatile("" : "+v"(lo));
                     const int lrow = lo / CPR;
-                    lane_off_step = POW2 ? lrow * F + (((lo % CPR) ^ ((RPI * wid + lrow) & SWZ)) * 8) : 0;
+                    lane_off_step = POW2 ? lrow * F + (((lo % CPR) ^ ((RPI * wid + lrow) & SWZ)) * (I8 ? 16 : 8)) : 0;
                 }
                 if (!DUAL || !was_early) {
                     if (p.persistent && s > p.s_begin) {
@@ -899,7 +925,17 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             fq[nt] = __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
                         }
                     };
-                    load_frags(0, fh[0], fl[0]);
+                    // NSPLIT == 4: the lane's 16 bytes of each digit for 32-column block b (cell 2 b + hsel of the row)
+                    v4i bd1[2][2], bd0[2][2];
+                    auto load_dig = [&](int b, v4i (&d1)[2], v4i (&d0)[2]) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const unsigned char *a = buf + nt * (32 * CPR * 16) + fa[b];
+                            d1[nt] = *reinterpret_cast<const v4i *>(a);
+                            d0[nt] = *reinterpret_cast<const v4i *>(a + PIECE_BYTES);
+                        }
+                    };
+                    if constexpr (I8) load_dig(0, bd1[0], bd0[0]); else load_frags(0, fh[0], fl[0]);
                     // DUAL: has the group of the coming group-step arrived?  One look at its counter (its members had a whole
                     // group-step for it) at the start of the piece whose closing barrier publishes the answer: the last
                     // piece, or (EIL) the one before it.
@@ -907,6 +943,41 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     if (DUAL && pc == PCHK && nxt_h && nxt_poll && tid == 0)
                         seen = __hip_atomic_load(ncnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (EIL && pc == NP - 1) go = __builtin_amdgcn_readfirstlane(nxt_h ? sFlag[1] : 0);
+                    if constexpr (I8) {
+                        constexpr int KBP = KP / 32;            // 32-column blocks per piece = DMA requests per wave and piece
+                        static_assert(NDMA == KBP, "one piece request per block");
+                        const v16i zero16 = {};
+#pragma unroll
+                        for (int b = 0; b < KBP; ++b) {
+                            const int kb = pc * KBP + b;
+                            if (b + 1 < KBP) load_dig(b + 1, bd1[(b + 1) & 1], bd0[(b + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // column tiles interleaved: the two products into amid[nt] are two issues apart (a dependent MFMA
+                            // issued back to back waits for the whole latency of its predecessor)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                a11[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd1[kb], bd1[b & 1][nt], kb == 0 ? zero16 : a11[nt], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                amid[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd1[kb], bd0[b & 1][nt], kb == 0 ? zero16 : amid[nt], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                amid[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd0[kb], bd1[b & 1][nt], amid[nt], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                a00[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd0[kb], bd0[b & 1][nt], kb == 0 ? zero16 : a00[nt], 0, 0, 0);
+                            // the piece requests go out in the first half of the piece so that the last has landed at its barrier
+                            constexpr int DPB = KBP >= 2 ? 2 : 1;
+                            if (b * DPB < NDMA) {
+#pragma unroll
+                                for (int j = 0; j < DPB; ++j) {
+                                    if (pc + 1 < NP) issue_dma(xprev, pc + 1, b * DPB + j);
+                                    else if (EIL && go) issue_dma(xnext, 0, b * DPB + j);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
 #pragma unroll
                     for (int ks = 0; ks < KSP; ++ks) {
                         const int kg = pc * KSP + ks;
@@ -937,11 +1008,29 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    }
                     XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
                     if (DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
                     __syncthreads();
                     XB_STAMP(7);   // piece DMA wait + barrier
+                }
+                if constexpr (I8) {
+                    // pre-activation = gin + row scale * (2^16 S11 + 2^8 (S10 + S01) + S00): every sum is exact, the fp32
+                    // combination rounds once per term (|S11| < 2^24)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const f32x4 sc = *reinterpret_cast<const f32x4 *>(sScale + (wid * 8 + 2 * rg + hsel) * 4);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int r = 4 * rg + g;
+                                const float t = __builtin_fmaf(65536.0f, (float)a11[nt][r],
+                                                               __builtin_fmaf(256.0f, (float)amid[nt][r], (float)a00[nt][r]));
+                                acc[nt][r] = __builtin_fmaf(sc[g], t, acc[nt][r]);
+                            }
+                        }
                 }
             }
 
@@ -971,6 +1060,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             for (int nt = 0; nt < 2; ++nt) {
                 unsigned phi[4], plo[4];
                 float hq[4], lq[4];
+                unsigned dg1[4], dg0[4];            // NSPLIT == 4: digit bytes of the four units
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
@@ -987,6 +1077,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     plo[rg] = (unsigned)__builtin_bit_cast(unsigned short, lo);
                     hq[rg] = (float)hi * 256.0f;                   // |h| < 1: below the e4m3 maximum by construction
                     lq[rg] = (hv - (float)hi) * 524288.0f;         // 2^19; |residual| <= 2^-11 |hi|
+                    if constexpr (I8) {
+                        // 16-bit fixed point of h (|q| <= 32512) as two balanced signed digits q = 256 d1 + d0
+                        const int q = (int)__builtin_rintf(hv * 32512.0f);
+                        const int d0 = ((q + 128) & 255) - 128;
+                        dg1[rg] = (unsigned)((q - d0) >> 8) & 255u;
+                        dg0[rg] = (unsigned)d0 & 255u;
+                    }
                 }
                 // lanes < 32 hold even units v[rg] = unit 2rg, lanes >= 32 the odd ones v[rg] = unit 2rg+1.
                 // v_permlane32_swap(vdst, src) exchanges vdst's upper half-wave with src's lower half-wave, so
@@ -1003,7 +1100,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
                     dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
                 }
-                if (NSPLIT == 2) {
+                if constexpr (I8) {
+                    // digit image of the 32 units, laid out like the q8 image below: rows 0..7 the d1 bytes of unit quads
+                    // 0..7, rows 8..15 their d0 bytes (third staging array)
+                    unsigned X = dg1[0] | (dg1[1] << 8) | (dg0[0] << 16) | (dg0[1] << 24);
+                    unsigned Y = dg1[2] | (dg1[3] << 8) | (dg0[2] << 16) | (dg0[3] << 24);
+                    auto r = __builtin_amdgcn_permlane32_swap(X, Y, false, false);
+                    const unsigned r0 = r[0], r1 = r[1];
+                    unsigned *dst = sT + 2 * 16 * ST_LD + nt * 32 + (lane & 31);
+                    dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+                    dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+                }
+                if (NSPLIT == 2 || I8) {
                     // q8 image of the 32 units: 16 dword rows in the place of the lo staging -- rows 0..7 the h8 bytes of unit
                     // quads 0..7, rows 8..15 their l8 bytes, so the 16-byte cell reads below need no change.
                     // X = {h8(u_a), h8(u_b), l8(u_a), l8(u_b)} of this lane's units (rg 0, 1), Y of (rg 2, 3); after the swap
@@ -1039,9 +1147,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (s + 1 < T) {
                 // publish h_t for the group -- also on the last step of a launch: the next launch (next step, or next time
                 // slab) starts from the exchange buffer (rows beyond the slab are scratch rows of the exchange buffer)
+                if constexpr (I8) {
+                    // one 16-byte cell per thread: occ 0, 1 = the d1 bytes of units 0..15 / 16..31 (part 0), occ 2, 3 = d0 (part 1)
+                    const unsigned *sd = sT + 2 * 16 * ST_LD + (occ * 4) * ST_LD + orow;
+                    const uint4 vd = make_uint4(sd[0], sd[ST_LD], sd[2 * ST_LD], sd[3 * ST_LD]);
+                    unsigned char *xb = reinterpret_cast<unsigned char *>(xg) + (size_t)(s & 1) * (XPAR * 2) +
+                                        (size_t)(occ >> 1) * (XPART * 2) + (size_t)orow * F + mb * LG_UNITS + (occ & 1) * 16;
+                    store16_sc1(xb, vd);
+                } else {
                 half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
                 store16_sc1(xcur, vhi);
                 if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
+                }
             }
             XB_STAMP(4);   // pointwise + exchange stores issued
             if (p.persistent && s + 1 < p.s_end) {
@@ -1102,8 +1219,9 @@ static size_t lstm_lds_bytes(int nsplit, bool dual)
     constexpr int KP = F < 128 ? F : 128;
     const int nparts = nsplit == 1 ? 1 : 2;
     const int ng = dual ? 2 : 1;
-    return (size_t)2 * nparts * LG_BN * KP * 2 + (size_t)nparts * 16 * ST_LD * 4 +
-           (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + 256 * 16;
+    const int es = nsplit == 4 ? 1 : 2, stp = nsplit == 4 ? 3 : nparts;     // lstm_kernel: ES, STP
+    return (size_t)2 * nparts * LG_BN * KP * es + (size_t)stp * 16 * ST_LD * 4 +
+           (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + 256 * 16 + 128 * 4;
 }
 
 template <int KS, int NSPLIT, bool DUAL>
@@ -1126,6 +1244,11 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const int members = F / LG_UNITS;
     const size_t lds = lstm_lds_bytes<KS>(p.nsplit, dual);
     const dim3 grid(g8 * members);
+    if constexpr (KS % 8 == 0 || KS == 4) {                    // int8-limb pieces: 64 or 128 columns
+        if (p.nsplit == 4) return dual ? launch_lstm_v<KS, 4, true>(p, grid, lds, stream) : launch_lstm_v<KS, 4, false>(p, grid, lds, stream);
+    } else if (p.nsplit == 4) {
+        return hipErrorInvalidValue;
+    }
     if (dual) {
         if (p.nsplit == 3) return launch_lstm_v<KS, 3, true>(p, grid, lds, stream);
         if (p.nsplit == 2) return launch_lstm_v<KS, 2, true>(p, grid, lds, stream);
@@ -1221,6 +1344,11 @@ template <int KS>
 static int lstm_occupancy_ks(int nsplit, bool dual)
 {
     const size_t lds = lstm_lds_bytes<KS>(nsplit, dual);
+    if constexpr (KS % 8 == 0 || KS == 4) {
+        if (nsplit == 4) return dual ? lstm_occupancy_v<KS, 4, true>(lds) : lstm_occupancy_v<KS, 4, false>(lds);
+    } else if (nsplit == 4) {
+        return 0;
+    }
     if (dual) {
         if (nsplit == 3) return lstm_occupancy_v<KS, 3, true>(lds);
         if (nsplit == 2) return lstm_occupancy_v<KS, 2, true>(lds);
@@ -1254,7 +1382,8 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (!lstm_supported_features(p.F) || p.nslab < 1 || p.s_begin < 0 || p.s_end > p.T || p.s_begin >= p.s_end)
         return hipErrorInvalidValue;
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
-    if (p.nsplit < 1 || p.nsplit > 3) return hipErrorInvalidValue;
+    if (p.nsplit < 1 || p.nsplit > 4) return hipErrorInvalidValue;
+    if (p.nsplit == 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
     switch (p.F / 16) {
     case 2: return launch_lstm_ks<2>(p, stream);
     case 4: return launch_lstm_ks<4>(p, stream);

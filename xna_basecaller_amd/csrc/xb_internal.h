@@ -99,7 +99,10 @@ struct LstmParams {
     unsigned *sync;              // per-group monotonic arrival counters, stride 32 words (zeroed once per layer and chunk slab)
     unsigned sync_base;          // arrivals per member already counted by earlier launches of this layer (time slabs)
     unsigned *error;             // set non-zero when a sync wait timed out
-    int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8)
+    int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8);
+                                 // 4: int8-limb recurrence (wq1, wq0, wscale below; y stays hi + q8 image for the next GEMM)
+    const int8_t *wq1, *wq0;     // nsplit == 4: (4F, F) balanced signed digits of round(W_hh / row scale * 32512), gate-interleaved rows
+    const float *wscale;         // nsplit == 4: (4F) row scale / 32512^2: the factor that turns the integer digit sums into W_hh h
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
     int dual;                    // 1: a workgroup serves two groups alternately (a launch then holds twice the groups)
