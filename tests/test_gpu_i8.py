@@ -20,7 +20,8 @@ def test_int8_limb_recurrence(monkeypatch, features, N, L):
     picks = sorted({0, 1, 63, 64, N - 1})
     ref = oracle.encode(x[picks], sd, features, nb, 3, expand_blanks=False)
     outs = {}
-    for name, i8, mode, dual in [("f16f8", "0", 2, "0"), ("i8", "1", 2, "0"), ("i8_step", "1", 1, "0"), ("i8_dual", "1", 2, "2")]:
+    for name, i8, mode, dual in [("f16f8", "0", 2, "0"), ("i8", "1", 2, "0"), ("i8_step", "1", 1, "0"), ("i8_dual", "1", 2, "2"),
+                                 ("i8x3", "2", 2, "0"), ("i8x3_dual_step", "2", 1, "2")]:
         monkeypatch.setenv("XB_LSTM_I8", i8)
         monkeypatch.setenv("XB_LSTM_DUAL", dual)
         ctx = _lib.Context(0, nb, 3, features, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8, lstm_mode=mode)
@@ -36,3 +37,7 @@ def test_int8_limb_recurrence(monkeypatch, features, N, L):
     assert e1.max() < 2e-4, e1.max()
     assert np.array_equal(outs["i8"], outs["i8_step"])
     assert np.array_equal(outs["i8"], outs["i8_dual"])
+    e2 = np.abs(outs["i8x3"][:, picks] - ref)
+    print("features %d: three products (XB_LSTM_I8=2) max %.2e rms %.2e" % (features, e2.max(), np.sqrt((e2 ** 2).mean())))
+    assert e2.max() < 3e-4, e2.max()
+    assert np.array_equal(outs["i8x3"], outs["i8x3_dual_step"]) and not np.array_equal(outs["i8x3"], outs["i8"])

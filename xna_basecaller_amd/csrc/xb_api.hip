@@ -73,7 +73,8 @@ struct xb_ctx {
     int w3_exp = 0, wih_exp[5] = {}, whh_exp[5] = {}, wl_exp = 0;   // q8 exponents (XB_PREC_F16F8)
     int8_t *whh_q1[5] = {}, *whh_q0[5] = {};   // int8-limb recurrence (lstm_i8): balanced digits of W_hh, gate-interleaved rows
     float *whh_sc[5] = {};                     // ... and the factor that turns the integer sum into the recurrent term
-    int lstm_i8 = 0;                           // XB_LSTM_I8=1 (with precision f16f8 / f16f8i): recurrence on int8 digits
+    int lstm_i8 = 0;                           // XB_LSTM_I8 (with precision f16f8 / f16f8i): recurrence on int8 digits; 1 = all
+                                               // four digit products, 2 = without d0 x d0
 
     // activations / workspaces
     float *d_signal = nullptr;
@@ -338,7 +339,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
     // ... and the occupancy calculator has to admit at least one such workgroup per CU (queried once per context); a
     // context that cannot keep the persistent kernel resident falls back to one launch per time step
-    const int rec_nsplit = (ctx->lstm_i8 && ctx->whh_q1[layer]) ? 4 : precision_nsplit(ctx);
+    const int rec_nsplit = (ctx->lstm_i8 && ctx->whh_q1[layer]) ? (ctx->lstm_i8 == 2 ? 5 : 4) : precision_nsplit(ctx);
     if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 0);
     if (ctx->lstm_dual_resident < 0) ctx->lstm_dual_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 1);
     const bool dual_ok = ctx->lstm_dual != 0 && ctx->lstm_dual_resident >= 1;
@@ -352,7 +353,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
     p.sync = ctx->sync; p.error = ctx->error; p.nsplit = precision_nsplit(ctx); p.w_exp = ctx->whh_exp[layer];
     if (ctx->lstm_i8 && ctx->whh_q1[layer]) {
-        p.nsplit = 4; p.wq1 = ctx->whh_q1[layer]; p.wq0 = ctx->whh_q0[layer]; p.wscale = ctx->whh_sc[layer];
+        p.nsplit = ctx->lstm_i8 == 2 ? 5 : 4; p.wq1 = ctx->whh_q1[layer]; p.wq0 = ctx->whh_q0[layer]; p.wscale = ctx->whh_sc[layer];
     }
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
     bool overlapped = false;
@@ -574,7 +575,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
-    if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) != 0;
+    if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \

@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // into two balanced signed 8-bit digits q = 256 d1 + d0; the four digit products run on v_mfma_i32_32x32x32_i8 (exact
     // int32 sums, three accumulator sets by weight 2^16 / 2^8 / 1) and are combined in fp32 once per step.  The exchange
     // image is one byte per element and part (part 0 = d1, part 1 = d0): half the DMA and fragment bytes of fp16 + q8.
-    constexpr bool I8 = NSPLIT == 4;
+    constexpr bool I8 = NSPLIT == 4 || NSPLIT == 5;
+    constexpr bool LOLO = NSPLIT == 4;          // NSPLIT == 5: without the d0 x d0 product (2^-16 of the leading one per term)
     constexpr int ES = I8 ? 1 : 2;              // bytes per element of one exchange part
     constexpr int CPR = KP * ES / 16;           // 16-byte cells per row per piece
     constexpr int SWZ = (CPR & -CPR) - 1;       // XOR mask that stays inside the row
@@ -963,9 +964,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
                                 amid[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd0[kb], bd1[b & 1][nt], amid[nt], 0, 0, 0);
+                            if constexpr (LOLO) {
 #pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-                                a00[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd0[kb], bd0[b & 1][nt], kb == 0 ? zero16 : a00[nt], 0, 0, 0);
+                                for (int nt = 0; nt < 2; ++nt)
+                                    a00[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd0[kb], bd0[b & 1][nt], kb == 0 ? zero16 : a00[nt], 0, 0, 0);
+                            }
                             // the piece requests go out in the first half of the piece so that the last has landed at its barrier
                             constexpr int DPB = KBP >= 2 ? 2 : 1;
                             if (b * DPB < NDMA) {
@@ -1027,7 +1030,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             for (int g = 0; g < 4; ++g) {
                                 const int r = 4 * rg + g;
                                 const float t = __builtin_fmaf(65536.0f, (float)a11[nt][r],
-                                                               __builtin_fmaf(256.0f, (float)amid[nt][r], (float)a00[nt][r]));
+                                                               LOLO ? __builtin_fmaf(256.0f, (float)amid[nt][r], (float)a00[nt][r])
+                                                                    : 256.0f * (float)amid[nt][r]);
                                 acc[nt][r] = __builtin_fmaf(sc[g], t, acc[nt][r]);
                             }
                         }
@@ -1219,7 +1223,7 @@ static size_t lstm_lds_bytes(int nsplit, bool dual)
     constexpr int KP = F < 128 ? F : 128;
     const int nparts = nsplit == 1 ? 1 : 2;
     const int ng = dual ? 2 : 1;
-    const int es = nsplit == 4 ? 1 : 2, stp = nsplit == 4 ? 3 : nparts;     // lstm_kernel: ES, STP
+    const int es = nsplit >= 4 ? 1 : 2, stp = nsplit >= 4 ? 3 : nparts;     // lstm_kernel: ES, STP
     return (size_t)2 * nparts * LG_BN * KP * es + (size_t)stp * 16 * ST_LD * 4 +
            (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + 256 * 16 + 128 * 4;
 }
@@ -1246,7 +1250,8 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
     const dim3 grid(g8 * members);
     if constexpr (KS % 8 == 0 || KS == 4) {                    // int8-limb pieces: 64 or 128 columns
         if (p.nsplit == 4) return dual ? launch_lstm_v<KS, 4, true>(p, grid, lds, stream) : launch_lstm_v<KS, 4, false>(p, grid, lds, stream);
-    } else if (p.nsplit == 4) {
+        if (p.nsplit == 5) return dual ? launch_lstm_v<KS, 5, true>(p, grid, lds, stream) : launch_lstm_v<KS, 5, false>(p, grid, lds, stream);
+    } else if (p.nsplit >= 4) {
         return hipErrorInvalidValue;
     }
     if (dual) {
@@ -1346,7 +1351,8 @@ static int lstm_occupancy_ks(int nsplit, bool dual)
     const size_t lds = lstm_lds_bytes<KS>(nsplit, dual);
     if constexpr (KS % 8 == 0 || KS == 4) {
         if (nsplit == 4) return dual ? lstm_occupancy_v<KS, 4, true>(lds) : lstm_occupancy_v<KS, 4, false>(lds);
-    } else if (nsplit == 4) {
+        if (nsplit == 5) return dual ? lstm_occupancy_v<KS, 5, true>(lds) : lstm_occupancy_v<KS, 5, false>(lds);
+    } else if (nsplit >= 4) {
         return 0;
     }
     if (dual) {
@@ -1382,8 +1388,8 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (!lstm_supported_features(p.F) || p.nslab < 1 || p.s_begin < 0 || p.s_end > p.T || p.s_begin >= p.s_end)
         return hipErrorInvalidValue;
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
-    if (p.nsplit < 1 || p.nsplit > 4) return hipErrorInvalidValue;
-    if (p.nsplit == 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
+    if (p.nsplit < 1 || p.nsplit > 5) return hipErrorInvalidValue;
+    if (p.nsplit >= 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
     switch (p.F / 16) {
     case 2: return launch_lstm_ks<2>(p, stream);
     case 4: return launch_lstm_ks<4>(p, stream);

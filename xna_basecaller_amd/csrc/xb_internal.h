@@ -100,7 +100,8 @@ struct LstmParams {
     unsigned sync_base;          // arrivals per member already counted by earlier launches of this layer (time slabs)
     unsigned *error;             // set non-zero when a sync wait timed out
     int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8);
-                                 // 4: int8-limb recurrence (wq1, wq0, wscale below; y stays hi + q8 image for the next GEMM)
+                                 // 4: int8-limb recurrence (wq1, wq0, wscale below; y stays hi + q8 image for the next GEMM);
+                                 // 5: the same without the d0 x d0 product
     const int8_t *wq1, *wq0;     // nsplit == 4: (4F, F) balanced signed digits of round(W_hh / row scale * 32512), gate-interleaved rows
     const float *wscale;         // nsplit == 4: (4F) row scale / 32512^2: the factor that turns the integer digit sums into W_hh h
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
