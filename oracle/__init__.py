@@ -15,6 +15,8 @@ from .oracle import (  # noqa: F401
     decode_scaled,
     pack,
     decode_batch,
+    ctc_indices,
+    ctc_logz,
     conv1d_silu,
     lstm,
     linear_crf,

@@ -47,6 +47,7 @@ def lib():
         _lib.xo_linear_crf.restype = C.c_int
         _lib.xo_encode.restype = C.c_int
         _lib.xo_num_threads.restype = C.c_int
+        _lib.xo_ctc_logz.restype = C.c_int
     return _lib
 
 
@@ -266,3 +267,38 @@ def encode(signal, state_dict, features, n_base, state_len, winlen=19, stride=5,
     if rc:
         raise MemoryError("xo_encode failed")
     return (scores, lo) if want_lstm_out else scores
+
+
+def ctc_indices(targets, n_base, state_len):
+    """prepare_ctc_scores' gather indices (crf/model.py:102-116): (stay_idx (N, n), move_idx (N, n-1)), n = Lt - state_len + 1."""
+    t = np.ascontiguousarray(targets, dtype=np.int32)
+    N, Lt = t.shape
+    n = Lt - (state_len - 1)
+    stay = np.zeros((N, n), np.int32)
+    move = np.zeros((N, max(n - 1, 0)), np.int32)
+    lib().xo_ctc_indices(_p(t, i32p), C.c_int(N), C.c_int(Lt), C.c_int(n_base), C.c_int(state_len), _p(stay, i32p), _p(move, i32p))
+    return stay, move
+
+
+def ctc_logz(scores, targets, target_lengths, n_base, state_len, semiring="log", want_grads=False):
+    """seqdist.ctc_simple logZ over the stay / move lattice of the targets (crf/model.py:118-135).  scores (T, N, C) with the
+    blank column.  Returns {'logz': (N,)} plus, with want_grads, 'stay' (T, N, n) and 'move' (T, N, n-1): the restricted
+    posteriors (Log) or, for semiring 'max', 'stay' = the one-hot Viterbi alignment (viterbi_alignments)."""
+    sc = _f32(scores)
+    T, N, Cc = sc.shape
+    stay_idx, move_idx = ctc_indices(targets, n_base, state_len)
+    n = stay_idx.shape[1]
+    tl = np.ascontiguousarray(target_lengths, dtype=np.int32)
+    logz = np.empty(N, np.float32)
+    gs = np.zeros((T, N, n), np.float32) if want_grads else None
+    gm = np.zeros((T, N, max(n - 1, 0)), np.float32) if (want_grads and semiring == "log") else None
+    rc = lib().xo_ctc_logz(_p(sc), C.c_int(T), C.c_int(N), C.c_int(Cc), _p(stay_idx, i32p), _p(move_idx, i32p), C.c_int(n),
+                           _p(tl, i32p), C.c_int(state_len), C.c_int(0 if semiring == "log" else 1), _p(logz), _p(gs), _p(gm))
+    if rc:
+        raise ValueError("xo_ctc_logz failed (%d): target_lengths outside [state_len, Lt]?" % rc)
+    out = {"logz": logz}
+    if want_grads:
+        out["stay"] = gs
+        if gm is not None:
+            out["move"] = gm
+    return out

@@ -885,6 +885,120 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* CTC-CRF loss scans (crf/model.py:102-135)                                             */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * prepare_ctc_scores (crf/model.py:102-116): targets (N, Lt) are CTC labels (0 = blank / padding), shifted to zero-based
+ * bases and clamped; with n = Lt - (sl - 1) target positions
+ *   stay_idx[b][l] = (sum_i targets[b][l + i] * nb^(sl - i - 1)) * E          l = 0 .. n-1
+ *   move_idx[b][l] = stay_idx[b][l + 1] + targets[b][l] + 1                   l = 0 .. n-2
+ * index the C = S * E score columns of a time step.
+ */
+XO_API void xo_ctc_indices(const int32_t *targets, int N, int Lt, int nb, int sl, int32_t *stay_idx, int32_t *move_idx)
+{
+    const int n = Lt - (sl - 1), E = nb + 1;
+    for (int b = 0; b < N; ++b) {
+        for (int l = 0; l < n; ++l) {
+            int64_t st = 0;
+            for (int i = 0; i < sl; ++i) {
+                int v = targets[(size_t)b * Lt + l + i] - 1;
+                if (v < 0) v = 0;
+                st += (int64_t)v * ipow(nb, sl - i - 1);
+            }
+            stay_idx[(size_t)b * n + l] = (int32_t)(st * E);
+        }
+        for (int l = 0; l + 1 < n; ++l) {
+            int v = targets[(size_t)b * Lt + l] - 1;
+            if (v < 0) v = 0;
+            move_idx[(size_t)b * (n - 1) + l] = stay_idx[(size_t)b * n + l + 1] + v + 1;
+        }
+    }
+}
+
+/*
+ * seqdist.ctc_simple.logZ (logZ_cupy at crf/model.py:122; viterbi_alignments at :135) restated -- "parity unpinned" like the
+ * decode: seqdist 0.0.4 is not in the tree.  With stay[t][l] = scores[t][b][stay_idx[b][l]], move[t][l] = scores[t][b][move_idx[b][l]]:
+ *   alpha_0[l] = (l == 0 ? one : zero);   alpha_{t+1}[l] = sum2(alpha_t[l] + stay[t][l], alpha_t[l-1] + move[t][l-1])
+ *   logZ[b] = alpha_T[len_b - 1]          (beta_T is `one` at position len_b - 1 and `zero` elsewhere)
+ *   beta_t[l] = sum2(stay[t][l] + beta_{t+1}[l], move[t][l] + beta_{t+1}[l+1])
+ * where len_b = target_lengths[b] + 1 - sl positions are in use, zero = -1e38 (seqdist's Log.zero), one = 0, and
+ *   semiring 0 (Log): sum2(x0, x1) = m + log(exp(x0 - m) + exp(x1 - m)), m = max(x0, x1), with the contract's exp / log;
+ *                     a missing neighbour (l - 1 < 0, l + 1 >= n) enters as `zero`, which changes nothing in binary32;
+ *   semiring 1 (Max): sum2 = max.
+ * Optional outputs (Log): the restricted posteriors = d logZ / d stay, d logZ / d move,
+ *   gstay[t][b][l] = exp(((alpha_t[l] + stay[t][l]) + beta_{t+1}[l]) - logZ),  gmove[t][b][l] = exp(((alpha_t[l] + move[t][l]) + beta_{t+1}[l+1]) - logZ);
+ * (Max): the Viterbi alignment, one-hot over positions: align[t][b][l] = 1 where the best path sits at position l before
+ *   step t (stay.grad + shifted move.grad of seqdist's viterbi_alignments); ties prefer the stay edge.
+ * scores (T, N, C) fp32; stay_idx (N, n), move_idx (N, n-1) from xo_ctc_indices; gstay / align (T, N, n), gmove (T, N, n-1).
+ */
+XO_API int xo_ctc_logz(const float *scores, int T, int N, int C, const int32_t *stay_idx, const int32_t *move_idx, int n,
+                       const int32_t *target_lengths, int sl, int semiring, float *logz, float *gstay, float *gmove)
+{
+    const float ZERO = -1e38f;
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (int b = 0; b < N; ++b) {
+        const int len = target_lengths[b] + 1 - sl;
+        if (len < 1 || len > n) { rc = -1; continue; }
+        float *alpha = (float *)malloc(sizeof(float) * (size_t)(T + 1) * n);
+        float *beta = (float *)malloc(sizeof(float) * (size_t)2 * n);
+        if (!alpha || !beta) { rc = -2; free(alpha); free(beta); continue; }
+        const int32_t *si = stay_idx + (size_t)b * n, *mi = move_idx + (size_t)b * (n - 1);
+        for (int l = 0; l < n; ++l) alpha[l] = l == 0 ? 0.0f : ZERO;
+        for (int t = 0; t < T; ++t) {
+            const float *row = scores + ((size_t)t * N + b) * C;
+            const float *a = alpha + (size_t)t * n;
+            float *an = alpha + (size_t)(t + 1) * n;
+            for (int l = 0; l < n; ++l) {
+                const float x0 = a[l] + row[si[l]];
+                const float x1 = l > 0 ? a[l - 1] + row[mi[l - 1]] : ZERO;
+                const float m = x0 > x1 ? x0 : x1;
+                an[l] = semiring ? m : m + xo_logf_i(xo_expf_i(x0 - m) + xo_expf_i(x1 - m));
+            }
+        }
+        const float lz = alpha[(size_t)T * n + len - 1];
+        if (logz) logz[b] = lz;
+        if (semiring == 0 && (gstay || gmove)) {
+            float *bn = beta, *bc = beta + n;
+            for (int l = 0; l < n; ++l) bn[l] = l == len - 1 ? 0.0f : ZERO;
+            for (int t = T - 1; t >= 0; --t) {
+                const float *row = scores + ((size_t)t * N + b) * C;
+                const float *a = alpha + (size_t)t * n;
+                for (int l = 0; l < n; ++l) {
+                    const float st = row[si[l]];
+                    const float mv = l + 1 < n ? row[mi[l]] : 0.0f;
+                    const float bnext = l + 1 < n ? bn[l + 1] : ZERO;
+                    if (gstay) gstay[((size_t)t * N + b) * n + l] = xo_expf_i(((a[l] + st) + bn[l]) - lz);
+                    if (gmove && l + 1 < n) gmove[((size_t)t * N + b) * (n - 1) + l] = xo_expf_i(((a[l] + mv) + bnext) - lz);
+                    const float x0 = st + bn[l];
+                    const float x1 = l + 1 < n ? mv + bnext : ZERO;
+                    const float m = x0 > x1 ? x0 : x1;
+                    bc[l] = m + xo_logf_i(xo_expf_i(x0 - m) + xo_expf_i(x1 - m));
+                }
+                float *tmp = bn; bn = bc; bc = tmp;
+            }
+        }
+        if (semiring == 1 && gstay) {
+            /* back-trace of the max path from position len - 1 at time T */
+            int l = len - 1;
+            for (int t = T - 1; t >= 0; --t) {
+                const float *row = scores + ((size_t)t * N + b) * C;
+                const float *a = alpha + (size_t)t * n;
+                float *out = gstay + ((size_t)t * N + b) * n;
+                for (int k = 0; k < n; ++k) out[k] = 0.0f;
+                const float x0 = a[l] + row[si[l]];
+                const float x1 = l > 0 ? a[l - 1] + row[mi[l - 1]] : ZERO;
+                if (!(x0 >= x1)) l -= 1;          /* the move edge l-1 -> l was strictly better */
+                out[l] = 1.0f;
+            }
+        }
+        free(alpha);
+        free(beta);
+    }
+    return rc;
+}
+
 XO_API void xo_set_num_threads(int n)
 {
 #ifdef _OPENMP

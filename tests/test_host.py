@@ -254,6 +254,32 @@ def test_fast5_reader_equals_bundle_path(tmp_path, vbz, vlen):
     assert [r.index for r in xreads.get_reads(str(d5), shard=(1, 2))] == [1, 3, 5]
 
 
+def test_read_loader_lookahead_is_bounded(tmp_path):
+    """Pool.imap has no backpressure: the loader hands jobs out as results are taken, so never more than
+    `lookahead` prepared reads exist ahead of a slow consumer; order and content equal the serial path."""
+    import time
+    from h5write import write_multi_fast5
+    recs = _fast5_records(24)
+    write_multi_fast5(str(tmp_path / "b.fast5"), recs, vbz=True)
+    serial = [r.read_id for r in xreads.get_reads(str(tmp_path))]
+    loader = xreads.ReadLoader(str(tmp_path), n_proc=3, lookahead=5)
+    got = []
+    for r in loader:
+        time.sleep(0.01)                                   # a slow device stage
+        got.append(r.read_id)
+    assert got == serial and 1 <= loader.max_pending <= 5
+    assert xreads.ReadLoader(str(tmp_path), n_proc=2).lookahead == 8
+
+
+def test_env_rank_world(monkeypatch):
+    from xna_basecaller_amd import dist as xdist
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert xdist.env_rank_world() == (0, 1)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    assert xdist.env_rank_world() == (3, 4)
+
+
 def test_hdf5_lite_basics(tmp_path):
     from h5write import H5Writer
     from xna_basecaller_amd import hdf5_lite
@@ -281,11 +307,42 @@ def test_hdf5_lite_basics(tmp_path):
     with pytest.raises(hdf5_lite.Hdf5Error):
         (tmp_path / "bad.h5").write_bytes(b"not hdf5" * 100)
         hdf5_lite.File(str(tmp_path / "bad.h5"))
-    # VBZ round trip on awkward data (wrap-around differences, odd lengths)
-    for n in (0, 1, 7, 8, 9, 1000):
+    # VBZ round trip on awkward data (wrap-around differences, odd lengths), both stream versions
+    for n in (0, 1, 3, 4, 5, 7, 8, 9, 1000):
         v = np.random.default_rng(n).integers(-32768, 32768, n).astype(np.int16)
-        enc = hdf5_lite.vbz_encode_int16(v, level=1)
-        assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(enc, [0, 2, 1, 1]), dtype="<i2"), v)
+        for version in (0, 1):
+            for level in (0, 1):
+                enc = hdf5_lite.vbz_encode_int16(v, level=level, version=version)
+                assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(enc, [version, 2, 1, level]), dtype="<i2"), v)
+
+
+def test_vbz_known_vectors():
+    """Streams written out by hand from the format descriptions (StreamVByte README: control bytes first, two bits per
+    value = byte count - 1, first value in the low bits; vbz_compression: version 0 widens to 32 bits, zig-zag of the
+    difference to the previous sample) -- independent of this package's own encoder.
+    samples 100, 101, 99, 400, -5 -> differences 100, 1, -2, 301, -405 -> zig-zag 200, 2, 3, 602, 809."""
+    from xna_basecaller_amd import hdf5_lite
+    want = np.array([100, 101, 99, 400, -5], dtype="<i2")
+    # version 0: keys (0, 0, 0, 1) -> 0x40, (1) -> 0x01; data c8 | 02 | 03 | 5a 02 | 29 03
+    v0 = bytes([10, 0, 0, 0, 0x40, 0x01, 0xC8, 0x02, 0x03, 0x5A, 0x02, 0x29, 0x03])
+    assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(v0, [0, 2, 1, 0]), dtype="<i2"), want)
+    # version 1 (svb16): one key bit per value, LSB first: 0, 0, 0, 1, 1 -> 0x18; same data bytes
+    v1 = bytes([10, 0, 0, 0, 0x18, 0xC8, 0x02, 0x03, 0x5A, 0x02, 0x29, 0x03])
+    assert np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(v1, [1, 2, 1, 0]), dtype="<i2"), want)
+    # the two layouts are NOT interchangeable: the version field decides (a version-0 stream read as svb16 is garbage)
+    assert not np.array_equal(np.frombuffer(hdf5_lite.vbz_decode(v0, [1, 2, 1, 0]), dtype="<i2"), want)
+    # version 0 without the delta / zig-zag flag: plain widened values 1, 256, 65535 -> keys (0, 1, 1) = 0x14
+    raw = bytes([6, 0, 0, 0, 0x14, 0x01, 0x00, 0x01, 0xFF, 0xFF])
+    assert np.frombuffer(hdf5_lite.vbz_decode(raw, [0, 2, 0, 0]), dtype="<u2").tolist() == [1, 256, 65535]
+    # our encoder produces exactly the hand-written version-0 stream
+    assert hdf5_lite.vbz_encode_int16(want, level=0, version=0) == v0
+    assert hdf5_lite.vbz_encode_int16(want, level=0, version=1) == v1
+    # version 1, 4-byte samples: 0/1/2/4-byte variant; values 0, 5, 300, 70000 -> zig-zag of differences 0, 10, 590, 139400
+    # codes (0, 1, 2, 3) -> 0xE4; data 0a | 4e 02 | 88 20 02 00
+    v4 = bytes([16, 0, 0, 0, 0xE4, 0x0A, 0x4E, 0x02, 0x88, 0x20, 0x02, 0x00])
+    assert np.frombuffer(hdf5_lite.vbz_decode(v4, [1, 4, 1, 0]), dtype="<i4").tolist() == [0, 5, 300, 70000]
+    with pytest.raises(hdf5_lite.Hdf5Error):
+        hdf5_lite.vbz_decode(v0[:-2], [0, 2, 1, 0])          # truncated data
 
 
 def test_new_style_typed_encoder_config():

@@ -86,14 +86,17 @@ def _gathered_results(results, loader, rank, world, window=256):
 
 
 def main(args):
-    rank, world = xdist.init_from_env()
     if args.read_ids is not None and not os.path.isfile(args.read_ids):
         raise FileNotFoundError(args.read_ids)
-    # the reader pool (8 worker processes, cli/basecaller.py:107-111) is forked BEFORE anything touches the GPU; under
-    # torchrun every rank only ever loads its own shard of the reads
+    # the reader pool (8 worker processes, cli/basecaller.py:107-111) is forked BEFORE anything touches the GPU: the shard
+    # comes from torchrun's environment alone, and the process group (whose nccl backend selects the device, i.e.
+    # initialises HIP and starts runtime threads) is only joined once the pool exists.  Under torchrun every rank only
+    # ever loads its own shard of the reads.
+    rank, world = xdist.env_rank_world()
     reads = get_reads(args.reads_directory, n_proc=8, recursive=args.recursive,
                       read_ids=column_to_set(args.read_ids), skip=args.skip, limit=args.max_reads,
                       shard=(rank, world) if world > 1 else None)
+    rank, world = xdist.init_from_env()
 
     init(args.seed, args.device)
     device = args.device

@@ -49,10 +49,12 @@ struct xb_ctx {
         float *h_signal = nullptr, *d_signal = nullptr;
         int8_t *h_seq = nullptr, *d_seq = nullptr;
         int32_t *h_len = nullptr, *d_len = nullptr;
+        unsigned *h_err = nullptr;             // snapshot of the device error word taken on the result stream behind this batch
         hipEvent_t h2d = nullptr, done = nullptr;
         int n = 0;
         bool busy = false;
     } slots[2];
+    bool pipeline_failed = false;          // a collected batch reported a lost rendezvous: every batch in flight fails with it
     hipStream_t stream_copy = nullptr;     // H2D of the next batch beside the compute of the current one
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
     size_t dep_next = 0;
@@ -71,6 +73,12 @@ struct xb_ctx {
     half_t *wl_hi = nullptr, *wl_lo = nullptr;
     float *bl = nullptr;
     int w3_exp = 0, wih_exp[5] = {}, whh_exp[5] = {}, wl_exp = 0;   // q8 exponents (XB_PREC_F16F8)
+    // fragment-major images of the GEMM B operands (gemm4p_kernel, xb_internal.h) and their k-tile strides; the input
+    // projections also as hi-only images for XB_PREC_F16F8_IN1
+    unsigned char *w3_f4 = nullptr, *wih_f4[5] = {}, *wih_f4h[5] = {}, *wl_f4 = nullptr;
+    size_t w3_ks = 0, wih_ks = 0, wih_ksh = 0, wl_ks = 0;
+    int gemm4 = 1;                             // XB_GEMM4=0: gemm8r_kernel (one workgroup per CU) instead of gemm4p_kernel (A/B comparisons)
+    std::vector<void *> wbufs;                 // weight allocations of the current xb_weights_ready (freed by the next one)
     int8_t *whh_q1[5] = {}, *whh_q0[5] = {};   // int8-limb recurrence (lstm_i8): balanced digits of W_hh, gate-interleaved rows
     float *whh_sc[5] = {};                     // ... and the factor that turns the integer sum into the recurrent term
     int lstm_i8 = 0;                           // XB_LSTM_I8 (with precision f16f8 / f16f8i): recurrence on int8 digits; 1 = all
@@ -242,11 +250,48 @@ void split_rows(const float *src, int rows, int cols, int ld, std::vector<half_t
         }
 }
 
+// Fragment-major image of a GEMM B operand for gemm4p_kernel (layout: xb_internal.h, GemmParams::b4).  `hi` / `lo` are
+// split_rows outputs with leading dimension ld (lo = the fp16 residual for nsplit 3, the q8 image for nsplit 2, unused for
+// nsplit 1); rows are padded with zeros to a multiple of 256 so that no tile needs a bounds check.
+void fragment_major(const std::vector<half_t> &hi, const std::vector<half_t> &lo, int rows, int ld, int K, int nsplit,
+                    std::vector<unsigned char> &out, size_t *kstride)
+{
+    const int rows4 = (rows + 255) & ~255, nt32 = rows4 / 32, npc = xb::gemm4_pieces(nsplit), nk = K / 32;
+    *kstride = (size_t)nt32 * npc * 1024;
+    out.assign((size_t)nk * *kstride, 0);
+    const unsigned char *hib = reinterpret_cast<const unsigned char *>(hi.data());
+    const unsigned char *lob = reinterpret_cast<const unsigned char *>(lo.data());
+    for (int kt = 0; kt < nk; ++kt)
+        for (int nt = 0; nt < nt32; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int r = nt * 32 + (l & 31), h = l >> 5;
+                if (r >= rows) continue;
+                unsigned char *blk = out.data() + (size_t)kt * *kstride + (size_t)nt * npc * 1024 + (size_t)l * 16;
+                const size_t e0 = (size_t)r * ld + (size_t)kt * 32;          // element offset of the row's k-tile
+                for (int ks = 0; ks < 2; ++ks) {
+                    memcpy(blk + ks * 1024, hib + (e0 + ks * 16 + h * 8) * 2, 16);
+                    if (nsplit == 3) memcpy(blk + (2 + ks) * 1024, lob + (e0 + ks * 16 + h * 8) * 2, 16);
+                }
+                if (nsplit == 2) {
+                    // q8 block of the 32 columns: [h8 x 32 | l8 x 32]; the B role reads l8 in lanes 0-31, h8 in lanes 32-63
+                    const unsigned char *q = lob + e0 * 2 + (h == 0 ? 32 : 0);
+                    memcpy(blk + 2 * 1024, q, 16);
+                    memcpy(blk + 3 * 1024, q + 16, 16);
+                }
+            }
+}
+
+// weight upload: the allocation belongs to the current weight set (ctx->wbufs), which the next xb_weights_ready releases
 template <typename Tp>
 int upload(xb_ctx *ctx, Tp **dst, const std::vector<Tp> &src)
 {
-    int rc = dev_alloc(ctx, dst, src.size());
-    if (rc) return rc;
+    void *p = nullptr;
+    const size_t bytes = (src.size() * sizeof(Tp) + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return fail(ctx, XB_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    ctx->wbufs.push_back(p);
+    *dst = reinterpret_cast<Tp *>(p);
     XB_HIP(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(Tp), hipMemcpyHostToDevice));
     return XB_OK;
 }
@@ -301,7 +346,11 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
         // main product only (the q8 images stay unused) -- in1_layers: bit l = input projection of layer l (diagnostic
         // XB_IN1_LAYERS, default all five)
-        if (ctx->cfg.precision == XB_PREC_F16F8_IN1 && ((ctx->in1_layers >> ng.layer) & 1)) g.nsplit = 1;
+        if (ctx->gemm4) { g.b4 = ctx->wih_f4[ng.layer]; g.b4_kstride = ctx->wih_ks; }
+        if (ctx->cfg.precision == XB_PREC_F16F8_IN1 && ((ctx->in1_layers >> ng.layer) & 1)) {
+            g.nsplit = 1;
+            if (ctx->gemm4) { g.b4 = ctx->wih_f4h[ng.layer]; g.b4_kstride = ctx->wih_ksh; }
+        }
         g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
         g.gin_n = n;                                                           // member-major gin (xb_internal.h)
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_BIAS_F32, st));
@@ -310,6 +359,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
         g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo; g.Nn = ctx->O; g.bias = ctx->bl;
         g.scale = c.scale; g.nb = c.n_base; g.expand = ng.expand; g.blank = c.blank_score;
         g.a_exp = 8; g.b_exp = ctx->wl_exp;
+        if (ctx->gemm4) { g.b4 = ctx->wl_f4; g.b4_kstride = ctx->wl_ks; }
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, st));
     }
     return XB_OK;
@@ -444,6 +494,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
         g.M = T * n; g.Nn = F; g.K = ctx->kp; g.lda = ctx->kp; g.ldb = ctx->kp;
         g.bias = ctx->b3; g.out_hi = ctx->x_hi[0]; g.out_lo = ctx->x_lo[0]; g.ldc = F; g.nsplit = nsplit;
         g.a_exp = 0; g.b_exp = ctx->w3_exp; g.out_exp = 0;
+        if (ctx->gemm4) { g.b4 = ctx->w3_f4; g.b4_kstride = ctx->w3_ks; }
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_SILU_SPLIT, ctx->stream));
     }
     // layer l reads gin[l & 1] while the next layer's input projection is written into the other buffer
@@ -576,6 +627,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
     if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
+    if (const char *e = getenv("XB_GEMM4")) ctx->gemm4 = atoi(e) != 0;
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \
@@ -658,6 +710,7 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
         if (sl.h_signal) (void)hipHostFree(sl.h_signal);
         if (sl.h_seq) (void)hipHostFree(sl.h_seq);
         if (sl.h_len) (void)hipHostFree(sl.h_len);
+        if (sl.h_err) (void)hipHostFree(sl.h_err);
         if (sl.h2d) (void)hipEventDestroy(sl.h2d);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
@@ -665,6 +718,7 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
     for (auto &e : ctx->deps) (void)hipEventDestroy(e);
     for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     for (auto &b : ctx->bufs) hipFree(b.p);
+    for (void *w : ctx->wbufs) hipFree(w);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
@@ -699,6 +753,12 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
             keys.push_back("encoder." + std::to_string(l) + ".rnn." + s);
     for (auto &k : keys)
         if (!need(k)) return fail(ctx, XB_ERR_STATE, "missing tensor '%s'", k.c_str());
+    // a second load_state_dict on a live context: nothing may still be reading the previous weight set
+    if (!ctx->wbufs.empty()) {
+        if (int rcs = sync_all(ctx)) return rcs;
+        for (void *w : ctx->wbufs) (void)hipFree(w);
+        ctx->wbufs.clear();
+    }
 
     int rc;
     if ((rc = upload(ctx, &ctx->w1, *need("encoder.0.conv.weight")))) return rc;
@@ -711,6 +771,10 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
     split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo, q8 ? &ctx->w3_exp : nullptr);
     if ((rc = upload(ctx, &ctx->w3_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->w3_lo, lo))) return rc;
+    const int ns = precision_nsplit(ctx);
+    std::vector<unsigned char> f4;
+    fragment_major(hi, lo, F, ctx->kp, ctx->kp, ns, f4, &ctx->w3_ks);
+    if ((rc = upload(ctx, &ctx->w3_f4, f4))) return rc;
     for (int l = 0; l < 5; ++l) {
         const std::string pre = "encoder." + std::to_string(4 + l) + ".rnn.";
         const float *wih = need(pre + "weight_ih_l0")->data(), *whh = need(pre + "weight_hh_l0")->data();
@@ -726,6 +790,12 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
         split_rows(wi.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->wih_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->wih_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->wih_lo[l], lo))) return rc;
+        fragment_major(hi, lo, 4 * F, F, F, ns, f4, &ctx->wih_ks);
+        if ((rc = upload(ctx, &ctx->wih_f4[l], f4))) return rc;
+        if (ctx->cfg.precision == XB_PREC_F16F8_IN1) {
+            fragment_major(hi, lo, 4 * F, F, F, 1, f4, &ctx->wih_ksh);
+            if ((rc = upload(ctx, &ctx->wih_f4h[l], f4))) return rc;
+        }
         split_rows(wh.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->whh_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->whh_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->whh_lo[l], lo))) return rc;
@@ -755,6 +825,8 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
     split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo, q8 ? &ctx->wl_exp : nullptr);
     if ((rc = upload(ctx, &ctx->wl_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->wl_lo, lo))) return rc;
+    fragment_major(hi, lo, ctx->O, F, F, ns, f4, &ctx->wl_ks);
+    if ((rc = upload(ctx, &ctx->wl_f4, f4))) return rc;
     if ((rc = upload(ctx, &ctx->bl, *need("encoder.9.linear.bias")))) return rc;
     ctx->host_w.clear();
     ctx->weights_ready = true;
@@ -850,6 +922,7 @@ XB_API int xb_crf_scans_dev(xb_ctx *ctx, const float *d_scores, int T, int n, in
     const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
     ScanOut so;
     so.alpha = d_alpha; so.beta = d_beta; so.logz = d_logz; so.post = d_post;
+    ctx->result_stream = ctx->stream;       // the scans run on the main stream (not on the async decode stream)
     return run_decode(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, nullptr, nullptr, nullptr, nullptr, nullptr, &so);
 }
 
@@ -953,6 +1026,7 @@ static int ensure_slot(xb_ctx *ctx, int slot)
     XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_signal), sizeof(float) * N * L, hipHostMallocDefault));
     XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_seq), N * T, hipHostMallocDefault));
     XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_len), sizeof(int32_t) * N, hipHostMallocDefault));
+    XB_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_err), sizeof(unsigned), hipHostMallocDefault));
     int rc = dev_alloc(ctx, &sl.d_signal, N * L);
     rc = rc ? rc : dev_alloc(ctx, &sl.d_seq, N * T);
     rc = rc ? rc : dev_alloc(ctx, &sl.d_len, N);
@@ -981,6 +1055,9 @@ XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, c
     hipStream_t rs = ctx->result_stream ? ctx->result_stream : ctx->stream;
     XB_HIP(ctx, hipMemcpyAsync(sl.h_seq, sl.d_seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, rs));
     XB_HIP(ctx, hipMemcpyAsync(sl.h_len, sl.d_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, rs));
+    // the error word as THIS batch left it (stream order: behind its recurrences and its decode), not as whatever batch
+    // happens to be running when the slot is collected finds it
+    XB_HIP(ctx, hipMemcpyAsync(sl.h_err, ctx->error, sizeof(unsigned), hipMemcpyDeviceToHost, rs));
     XB_HIP(ctx, hipEventRecord(sl.done, rs));
     sl.n = n;
     sl.busy = true;
@@ -998,11 +1075,16 @@ XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_le
     sl.busy = false;
     memcpy(seq, sl.h_seq, (size_t)sl.n * ctx->T);
     if (seq_len) memcpy(seq_len, sl.h_len, sizeof(int32_t) * (size_t)sl.n);
-    // the persistent recurrence reports a lost rendezvous through the error word: results would be garbage
-    unsigned e = 0;
-    XB_HIP(ctx, hipMemcpy(&e, ctx->error, sizeof e, hipMemcpyDeviceToHost));
-    if (e != 0) {
-        (void)hipMemset(ctx->error, 0, sizeof(unsigned));
+    // the persistent recurrence reports a lost rendezvous through the error word (snapshot taken behind this batch):
+    // results would be garbage.  The word is not cleared while another batch is in flight -- that batch fails too (it ran
+    // on a device in an unknown state) -- and is reset once the pipeline has drained.
+    if (*sl.h_err != 0) ctx->pipeline_failed = true;
+    if (ctx->pipeline_failed) {
+        if (!ctx->slots[0].busy && !ctx->slots[1].busy) {
+            (void)sync_all(ctx);
+            (void)hipMemset(ctx->error, 0, sizeof(unsigned));
+            ctx->pipeline_failed = false;
+        }
         return fail(ctx, XB_ERR_DEVICE, "LSTM inter-workgroup sync timed out (persistent kernel was not fully resident?)");
     }
     return XB_OK;

@@ -833,6 +833,162 @@ hipError_t launch_nb(const xb::DecodeParams &p, int vw, hipStream_t stream)
     return launch_nb_lps<NB, 1, false>(p, vw, stream);
 }
 
+
+// ======================================================================================================================
+// CTC-CRF loss scans: seqdist.ctc_simple's logZ over the stay / move lattice of a target sequence
+// (CTC_CRF.ctc_loss / ctc_viterbi_alignments, ub-bonito/bonito/crf/model.py:102-135; xb_internal.h CtcParams).
+// One workgroup per chunk, CTC_BS threads, position l of the target handled by thread l % CTC_BS (CTC_PMAX positions per
+// thread at most); the position vector lives in LDS (double buffered, one barrier per time step); the two gathered
+// scores a position needs per step come from the score row through a CTC_RD-deep register ring so that their latency is
+// off the step's dependency chain.  Arithmetic: the decode's contract (xb_expf / xb_logf, sum2 = max, exp, exp, add, log in
+// the order stay term, move term), written independently of oracle/xna_oracle.c: xo_ctc_logz and bit-equal to it.
+// ======================================================================================================================
+constexpr int CTC_BS = 256, CTC_PMAX = 8, CTC_RD = 4;
+constexpr float CTC_ZERO = -1e38f;               // seqdist's Log.zero / Max.zero
+
+template <bool MAXS>
+__device__ __forceinline__ float ctc_sum2(float x0, float x1)
+{
+    const float m = x0 > x1 ? x0 : x1;
+    if (MAXS) return m;
+    return m + xb_logf(xb_expf(x0 - m) + xb_expf(x1 - m));
+}
+
+template <bool MAXS>
+__global__ __launch_bounds__(CTC_BS) void ctc_scan_kernel(xb::CtcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ctc_smem[];
+    float *vec = reinterpret_cast<float *>(ctc_smem);            // [2][n + 2]: slot l + 1 = position l, slots 0 and n + 1 = `zero`
+    const int tid = threadIdx.x, b = blockIdx.x, n = p.n, T = p.T;
+    const int len = p.tlen[b] + 1 - p.sl;
+    if (len < 1 || len > n) {
+        if (tid == 0) atomicOr(p.error, 2u);
+        return;
+    }
+    const int32_t *si = p.stay_idx + (size_t)b * n, *mi = p.move_idx + (size_t)b * (n - 1);
+    const float *srow = p.scores + (size_t)b * p.C;
+    const size_t tstride = (size_t)p.N * p.C;
+    float *stash = p.alpha ? p.alpha + (size_t)b * (T + 1) * n : nullptr;
+    const int vs = n + 2;
+    // this thread's positions and their gather columns: stay (own), move into the position (l - 1 -> l), move out of it (l -> l + 1)
+    int cs[CTC_PMAX], cin[CTC_PMAX], cout[CTC_PMAX];
+#pragma unroll
+    for (int k = 0; k < CTC_PMAX; ++k) {
+        const int l = tid + k * CTC_BS;
+        cs[k] = l < n ? si[l] : 0;
+        cin[k] = (l > 0 && l < n) ? mi[l - 1] : 0;
+        cout[k] = l + 1 < n ? mi[l] : 0;
+    }
+    for (int i = tid; i < 2 * vs; i += CTC_BS) vec[i] = CTC_ZERO;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CTC_PMAX; ++k) {
+        const int l = tid + k * CTC_BS;
+        if (l < n) {
+            const float a0 = l == 0 ? 0.0f : CTC_ZERO;
+            vec[l + 1] = a0;
+            if (stash) stash[l] = a0;
+        }
+    }
+    __syncthreads();
+
+    // ---- forward: alpha_{t+1}[l] = sum2(alpha_t[l] + stay[t][l], alpha_t[l-1] + move[t][l-1])
+    float rs[CTC_RD][CTC_PMAX], rm[CTC_RD][CTC_PMAX];
+    auto fetch = [&](int t, float (&s_)[CTC_PMAX], float (&m_)[CTC_PMAX], const int (&cm)[CTC_PMAX]) {
+        const float *row = srow + (size_t)(t < 0 ? 0 : (t >= T ? T - 1 : t)) * tstride;
+#pragma unroll
+        for (int k = 0; k < CTC_PMAX; ++k)
+            if (tid + k * CTC_BS < n) {
+                s_[k] = row[cs[k]];
+                m_[k] = row[cm[k]];
+            }
+    };
+#pragma unroll
+    for (int d = 0; d < CTC_RD; ++d) fetch(d, rs[d], rm[d], cin);
+    int cur = 0;
+    for (int t0 = 0; t0 < T; t0 += CTC_RD) {
+#pragma unroll
+        for (int d = 0; d < CTC_RD; ++d) {
+            const int t = t0 + d;
+            if (t < T) {                                   // uniform
+                const float *vc = vec + cur * vs;
+                float *vn = vec + (cur ^ 1) * vs;
+#pragma unroll
+                for (int k = 0; k < CTC_PMAX; ++k) {
+                    const int l = tid + k * CTC_BS;
+                    if (l < n) {
+                        const float x0 = vc[l + 1] + rs[d][k];
+                        const float x1 = l > 0 ? vc[l] + rm[d][k] : CTC_ZERO;
+                        const float v = ctc_sum2<MAXS>(x0, x1);
+                        vn[l + 1] = v;
+                        if (stash) stash[(size_t)(t + 1) * n + l] = v;
+                    }
+                }
+                fetch(t + CTC_RD, rs[d], rm[d], cin);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+    const float lz = vec[cur * vs + len];                  // alpha_T[len - 1]
+    if (tid == 0 && p.logz) p.logz[b] = lz;
+    if (!stash) return;
+    __syncthreads();
+
+    if (!MAXS) {
+        // ---- backward with the restricted posteriors: beta_t[l] = sum2(stay[t][l] + beta_{t+1}[l], move[t][l] + beta_{t+1}[l+1])
+        for (int i = tid; i < 2 * vs; i += CTC_BS) vec[i] = CTC_ZERO;
+        __syncthreads();
+        if (tid == 0) vec[len] = 0.0f;                     // beta_T: `one` at position len - 1
+        __syncthreads();
+        cur = 0;
+#pragma unroll
+        for (int d = 0; d < CTC_RD; ++d) fetch(T - 1 - d, rs[d], rm[d], cout);
+        for (int t0 = T - 1; t0 >= 0; t0 -= CTC_RD) {
+#pragma unroll
+            for (int d = 0; d < CTC_RD; ++d) {
+                const int t = t0 - d;
+                if (t >= 0) {
+                    const float *vc = vec + cur * vs;
+                    float *vn = vec + (cur ^ 1) * vs;
+#pragma unroll
+                    for (int k = 0; k < CTC_PMAX; ++k) {
+                        const int l = tid + k * CTC_BS;
+                        if (l < n) {
+                            const float a = stash[(size_t)t * n + l];
+                            const float st = rs[d][k], mv = rm[d][k];
+                            const float bn = vc[l + 1];
+                            const float bx = l + 1 < n ? vc[l + 2] : CTC_ZERO;
+                            if (p.gstay) p.gstay[((size_t)t * p.N + b) * n + l] = xb_expf(((a + st) + bn) - lz);
+                            if (p.gmove && l + 1 < n) p.gmove[((size_t)t * p.N + b) * (n - 1) + l] = xb_expf(((a + mv) + bx) - lz);
+                            const float x0 = st + bn;
+                            const float x1 = l + 1 < n ? mv + bx : CTC_ZERO;
+                            vn[l + 1] = ctc_sum2<false>(x0, x1);
+                        }
+                    }
+                    fetch(t - CTC_RD, rs[d], rm[d], cout);
+                    __syncthreads();
+                    cur ^= 1;
+                }
+            }
+        }
+    } else if (p.gstay) {
+        // ---- back-trace of the max path (one lane; T dependent steps): the alignment rows were zeroed by the host
+        __threadfence_block();
+        if (tid == 0) {
+            int l = len - 1;
+            for (int t = T - 1; t >= 0; --t) {
+                const float *row = srow + (size_t)t * tstride;
+                const float *a = stash + (size_t)t * n;
+                const float x0 = a[l] + row[si[l]];
+                const float x1 = l > 0 ? a[l - 1] + row[mi[l - 1]] : CTC_ZERO;
+                if (!(x0 >= x1)) l -= 1;                    // the move edge was strictly better (ties prefer the stay edge)
+                p.gstay[((size_t)t * p.N + b) * n + l] = 1.0f;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace xb {
@@ -871,5 +1027,18 @@ hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream)
     default: return hipErrorInvalidValue;
     }
 }
+
+
+hipError_t launch_ctc_scan(const CtcParams &p, hipStream_t stream)
+{
+    if (p.T < 1 || p.N < 1 || p.n < 1 || p.n > CTC_BS * CTC_PMAX || p.C < 1 || !p.scores || !p.stay_idx || !p.move_idx || !p.tlen || !p.error)
+        return hipErrorInvalidValue;
+    if ((p.gstay || p.gmove) && !p.alpha) return hipErrorInvalidValue;
+    const size_t lds = sizeof(float) * 2 * (size_t)(p.n + 2);
+    if (p.semiring) hipLaunchKernelGGL(ctc_scan_kernel<true>, dim3(p.N), dim3(CTC_BS), lds, stream, p);
+    else hipLaunchKernelGGL(ctc_scan_kernel<false>, dim3(p.N), dim3(CTC_BS), lds, stream, p);
+    return hipGetLastError();
+}
+int ctc_max_positions() { return CTC_BS * CTC_PMAX; }
 
 }  // namespace xb

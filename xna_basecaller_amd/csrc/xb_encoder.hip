@@ -203,44 +203,73 @@ __device__ __forceinline__ bool gemm_tile_origin(const xb::GemmParams &p, int &m
     return true;
 }
 
-// epilogue shared by the GEMM kernels: a wave holds 4 x 2 accumulator tiles of 32x32 (rows wm*128.., cols wn*64..);
-// a lane holds column (lane & 31) and 16 rows of each tile.  The bias is loaded ONCE, ahead of all stores: a load inside the
-// store loop makes every store wait (vmcnt counts stores too) for the one before it.
+// epilogue shared by the GEMM kernels: a wave holds 4 x 2 accumulator tiles of 32x32 whose origin is (mw, nw): rows
+// mw .. mw + 127, columns nw .. nw + 63 (nw a multiple of 64); a lane holds column (lane & 31) and 16 rows of each tile.
+// The bias is loaded ONCE, ahead of all stores: a load inside the store loop makes every store wait (vmcnt counts stores
+// too) for the one before it.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const floatx16 (&acc)[4][2], int m0, int n0,
-                                              int wm, int wn, int lane)
+__device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const floatx16 (&acc)[4][2], int mw, int nw, int lane)
 {
+    if (mw >= p.M || nw >= p.Nn) return;         // a wave wholly outside the matrix (edge tiles)
     float bj[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const int n = nw + j * 32 + (lane & 31);
         bj[j] = (p.bias && n < p.Nn) ? p.bias[n] : 0.0f;
     }
-    if (EPI == xb::EPI_BIAS_F32 && m0 + GBM <= p.M && n0 + GBN <= p.Nn && (p.gin_n == 0 || p.gin_n % 128 == 0)) {
-        // interior tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset.  With the member-major gin
-        // layout a WAVE's 128 rows (m0 + wm * 128) lie inside one time step whenever gin_n is a multiple of 128 (the
-        // reference's shipped batch size 384 included), its 64 columns lie in one member block and the row stride is
-        // 128 floats.
+    const bool interior = mw + 128 <= p.M && nw + 64 <= p.Nn;
+    if (EPI == xb::EPI_BIAS_F32 && interior && (p.gin_n == 0 || p.gin_n >= 43)) {
+        // interior wave tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset.  Member-major gin
+        // (xb_internal.h): row m = t * n + chunk lives at ((t * MB + member) * n + chunk) * 128; the wave's 64 columns lie
+        // in one member block.  Its 128 rows start at (t0, c0) and cross into the next time step where c0 + r reaches n
+        // (at most three times for n >= 43): each crossing adds (MB - 1) * n rows of 128 floats.  When the rows stay
+        // inside one time step (always so for n a multiple of 128) the offsets are compile-time multiples of the stride.
         const int ld = p.gin_n ? 128 : p.ldc;
-        float *tile = p.gin_n ? p.out_f32 + xb::gin_offset((size_t)(m0 + wm * 128), n0 + wn * 64, p.gin_n, p.Nn)
-                              : p.out_f32 + (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);
+        float *tile;
+        int c0 = 0, n = 1 << 30;
+        long long wrap = 0;
+        if (p.gin_n) {
+            n = p.gin_n;
+            const int t0 = mw / n;
+            c0 = mw - t0 * n;
+            const int MB = p.Nn >> 7;
+            tile = p.out_f32 + (((size_t)t0 * MB + (size_t)(nw >> 7)) * n + c0) * 128 + (nw & 127);
+            wrap = (long long)(MB - 1) * n * 128;
+        } else {
+            tile = p.out_f32 + (size_t)mw * p.ldc + nw;
+        }
         const int loff = (4 * (lane >> 5)) * ld + (lane & 31);
+        if (c0 + 128 <= n) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
+                for (int r = 0; r < 16; ++r) {
+                    float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
 #pragma unroll
-                // non-temporal: 12.6 GB per layer that nobody reads again before the L2 / Infinity Cache have turned over
-                for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
-            }
+                    // non-temporal: 12.6 GB per layer that nobody reads again before the L2 / Infinity Cache have turned over
+                    for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
+                }
+        } else {
+            const int cl = c0 + 4 * (lane >> 5);          // chunk index of this lane's row 0 (before wrapping)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const int c = cl + rr;
+                    const int k = (c >= n) + (c >= 2 * n) + (c >= 3 * n);
+                    float *rowp = tile + (size_t)rr * ld + (long long)k * wrap;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
+                }
+        }
         return;
     }
-    if (EPI == xb::EPI_SILU_SPLIT && m0 + GBM <= p.M && n0 + GBN <= p.Nn) {
+    if (EPI == xb::EPI_SILU_SPLIT && interior) {
         // interior tile of the conv3 GEMM: hi as fp16, second part as fp16 residual or q8 bytes; no bounds checks
-        const size_t tile = (size_t)(m0 + wm * 128) * p.ldc + (n0 + wn * 64);       // element offset of the wave's tile
+        const size_t tile = (size_t)mw * p.ldc + nw;       // element offset of the wave's tile
         const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
-        unsigned char *q8base = reinterpret_cast<unsigned char *>(p.out_lo) + tile * 2;    // n0 + wn*64 is a multiple of 32
+        unsigned char *q8base = reinterpret_cast<unsigned char *>(p.out_lo) + tile * 2;    // nw is a multiple of 32
         const int qoff = (4 * (lane >> 5)) * p.ldc * 2 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -272,14 +301,14 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            const int n = nw + j * 32 + (lane & 31);
             if (n >= p.Nn) continue;
             const float bias = bj[j];
             int ocol = n;
             if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
                 const float v = acc[i][j][r] + bias;
                 if (EPI == xb::EPI_BIAS_F32) {
@@ -541,7 +570,298 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     // the epilogue's per-lane indices must not be computed (and kept in registers) ahead of the main loop
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    gemm_epilogue<EPI>(p, acc, m0, n0, wr, wc, lane_e);
+    gemm_epilogue<EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, lane_e);
+}
+
+// ======================================================================================
+// gemm4p_kernel: the product's GEMM (round 3).  The same contraction as gemm8r_kernel, bit for bit (per accumulator the
+// products arrive in the same order), with TWO workgroups per CU:
+//   * 128 (M) x 256 (N) block tile, BK = 32, 4 waves side by side in N, each wave 128 x 64 = 4 x 2 MFMA 32x32 tiles.  Two
+//     independent 4-wave workgroups share a CU (2 waves per SIMD, 256 registers each, 48 KiB of LDS each): a tile is only
+//     24 k-tiles deep here (K = 768), so prologue and epilogue are a third of a workgroup's life, and one workgroup's
+//     runs under the other's MFMA clusters; the hardware interleaves the two main loops.
+//   * B (the weights) never touches LDS.  With the waves side by side in N no two waves share a B row, so each wave
+//     loads its own fragments straight into registers from a FRAGMENT-MAJOR weight image built once on the host
+//     (xb_api.hip: fragment_major): [k-tile][32-row block][piece][lane][16 B], i.e. every wave-instruction reads 1 KiB of
+//     consecutive bytes.  LDS carries only the A tile (shared by the four waves): 16 ds_read_b128 per wave and k-tile
+//     instead of 28, no ds_write at all.
+//   * TWO k-tiles of both operands are in flight (24 KiB per wave):
+//       A by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a ring of three stages, two tiles ahead;
+//       B in two register sets (even / odd k-tile, the loop is unrolled by two), every piece reloaded for tile t + 2 right
+//       behind its last MFMA of tile t.  These loads are inline asm so that hipcc neither counts them nor drains the
+//       LDS-DMAs for them (cdna_hip_programming.md 5, trap (b)); every wait is a counted s_waitcnt written here:
+//         per wave and k-tile NA LDS-DMAs, then the B pieces in groups g0, g1(, g2); issue order A(t) B(t) A(t+1) B(t+1) ..
+//         top of tile t (A(t) landed):      vmcnt(2 NB + NA)        -- everything younger than A(t) may be in flight
+//         before the MFMAs of B group k:    vmcnt(2 NB + 2 NA - gk) -- the gk oldest are that group
+//       (loads return in order; past the last tile the same tiles are loaded again, so the counts never change).
+//   * the A fragments are read one half sub-phase ahead (32 registers live), which is what makes room for the second B
+//     set: 128 accumulators + 64 B + 32 A.
+//   * the member-major gin epilogue takes any batch: a wave's 128 rows may cross into the next time step (gemm_epilogue).
+// What bounds it (round 3 measurements): with 4-byte operands (fp16 + q8 image) a 256 x 256 output patch
+// per CU needs 64-96 KiB from L2 per k-tile against 2048 MFMA-pipe cycles -- 32-47 B/clk, which IS what a CU's vector
+// memory path delivers (~70 GB/s per CU from L2, MI355X_MICROARCH.md); ablated builds without the loop's loads and the
+// epilogue's stores ran at the MFMA rate (5.0 ms per LSTM-input GEMM), each of the two costs ~2.2 ms and the two add up.
+// De-phasing the workgroups' starts, doubling the loads in flight (this kernel vs its one-tile-deep predecessor: 46.7 vs
+// 47.9 ms per five GEMMs) and the workgroup shape (one 256 x 256 workgroup per CU, gemm8r: 50 ms) move it by a few percent:
+// the bytes per element are the lever that is left.
+// ======================================================================================
+constexpr int G4_BM = 128, G4_BN = 256, G4_THREADS = 256;
+
+__device__ __forceinline__ bool gemm4_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
+{
+    const int MT = (p.M + G4_BM - 1) / G4_BM, NT = (p.Nn + G4_BN - 1) / G4_BN;
+    const int SN = NT < 4 ? NT : 4, SM = 64 / SN;            // 64 workgroups per XCD side by side (two per CU)
+    const int ngroups = (NT + SN - 1) / SN, msup = (MT + SM - 1) / SM;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int q = (j >> 6) * 8 + xcd, w = j & 63;            // super-tile id, slot in it
+    if (q >= msup * ngroups || w >= SM * SN) return false;
+    const int mt = (q / ngroups) * SM + w / SN, nt = (q % ngroups) * SN + w % SN;
+    if (mt >= MT || nt >= NT) return false;
+    m0 = mt * G4_BM;
+    n0 = nt * G4_BN;
+    return true;
+}
+
+template <int EPI, int NSPLIT>
+__global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
+{
+    constexpr int NPA = NSPLIT == 1 ? 1 : 2;   // A parts in LDS: hi (+ lo, or the q8 image)
+    constexpr int NPC = NSPLIT == 1 ? 2 : 4;   // B pieces (16 B per lane) per 32-row block and k-tile
+    constexpr int PARTB = 128 * 64;            // one A part of a stage: 128 rows x 32 halves
+    constexpr int STB = NPA * PARTB;           // stage bytes
+    constexpr int NA = 2 * NPA, NB = 2 * NPC;  // LDS-DMAs / B loads per wave and k-tile
+    constexpr int INFL = 2 * NB + 2 * NA;      // loads in flight once a tile's DMAs are issued
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];      // [3 stages][STB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int m0, n0;
+    if (!gemm4_tile_origin(p, m0, n0)) return;
+    const int nk = p.K / GBK;
+
+    // ---- A: lane i of wave w fills, per part, LDS cells of rows 16 w + (i >> 2) and 64 + that; cell (i & 3) of a row holds
+    //      source cell (i & 3) ^ ((row >> 2) & 3).  Rows past the matrix end are clamped to the last row.
+    unsigned offs[2];
+    {
+        const int r0 = tid >> 2, sc = ((tid & 3) ^ ((tid >> 4) & 3)) * 16;
+        const int Mrem = p.M - 1 - m0;
+        offs[0] = (unsigned)((r0 > Mrem ? Mrem : r0) * p.lda * 2 + sc);
+        offs[1] = (unsigned)((r0 + 64 > Mrem ? Mrem : r0 + 64) * p.lda * 2 + sc);
+    }
+    const unsigned char *const tA_hi = reinterpret_cast<const unsigned char *>(p.a_hi + (size_t)m0 * p.lda);
+    const unsigned char *const tA_lo = reinterpret_cast<const unsigned char *>(p.a_lo + (size_t)m0 * p.lda);
+    auto dma_a = [&](int t, int stage) {
+        const size_t kb = (size_t)t * (GBK * 2);
+        unsigned char *dst = smem_raw + stage * STB + wid * 1024;
+#pragma unroll
+        for (int part = 0; part < NPA; ++part)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)((part ? tA_lo : tA_hi) + kb + offs[h]),
+                    (__attribute__((address_space(3))) void *)(dst + part * PARTB + h * 4096), 16, 0, 0);
+    };
+
+    // ---- B: this wave's two 32-row blocks; lane byte offsets for block 0 / 1 (the pieces are immediates)
+    const unsigned boff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(n0 + wid * 64) >> 5) * NPC * 1024u));
+    const unsigned char *const tB = p.b4 + boff;       // wave-uniform by construction: an SGPR pair for the asm loads
+    const size_t bks = p.b4_kstride;
+    const unsigned voff0 = (unsigned)lane * 16, voff1 = voff0 + NPC * 1024;
+    u32x4 bE[2][NPC], bO[2][NPC];               // even / odd k-tile
+#define G4P_LDB(dst, base, j, pc)                                                               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"((j) ? voff1 : voff0), "s"(base), "i"((pc) * 1024))
+#define G4P_LDB_GROUP(bS, base, pc)                                                             \
+    do {                                                                                        \
+        G4P_LDB(bS[0][(pc)], base, 0, pc);                                                      \
+        G4P_LDB(bS[1][(pc)], base, 1, pc);                                                      \
+    } while (0)
+    // counted waits that also make the named registers "written here" for the compiler
+#define G4P_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(n))
+#define G4P_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(n))
+
+    // ---- A fragment read offsets (bytes) inside a part: row (lane & 31) of a 32-row tile, cell c ^ ((row >> 2) & 3)
+    const int hs = lane >> 5, sw = (lane >> 2) & 3;
+    unsigned la[2], lqa[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        la[j] = (unsigned)((lane & 31) * 64 + (((2 * j + hs) ^ sw) * 16));       // fp16 k-step j
+        lqa[j] = (unsigned)((lane & 31) * 64 + (((2 * hs + j) ^ sw) * 16));      // q8 image, A role: lanes 0-31 h8, 32-63 l8
+    }
+    const int sca = 127 - p.a_exp - 11, scb = 127 - p.b_exp;      // E8M0 scale bytes: 2^-(a_exp + b_exp + 11) in all
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+#define G4P_SB() __builtin_amdgcn_sched_barrier(0)
+    // fragments of two 32-row tiles (ih = 0: rows 0..63, ih = 1: rows 64..127) of one part and k-step / of the q8 image
+#define G4P_RD_H(d, sa, part, ih, ks)                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+        d[i_] = *reinterpret_cast<const half8 *>((sa) + (part) * PARTB + ((ih) * 2 + i_) * 2048 + la[(ks)])
+#define G4P_RD_Q(d, sa, ih)                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
+        const v4i x_ = *reinterpret_cast<const v4i *>((sa) + PARTB + ((ih) * 2 + i_) * 2048 + lqa[0]); \
+        const v4i y_ = *reinterpret_cast<const v4i *>((sa) + PARTB + ((ih) * 2 + i_) * 2048 + lqa[1]); \
+        d[i_] = __builtin_shufflevector(x_, y_, 0, 1, 2, 3, 4, 5, 6, 7);                        \
+    }
+#define G4P_F16(A_, ih, bS, pc)                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                        \
+            acc[(ih) * 2 + i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[i_], __builtin_bit_cast(half8, bS[j_][(pc)]), \
+                                                                          acc[(ih) * 2 + i_][j_], 0, 0, 0)
+#define G4P_F8(A_, ih, bS)                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                      \
+            const v8i bq_ = __builtin_shufflevector(__builtin_bit_cast(v4i, bS[j_][2]), __builtin_bit_cast(v4i, bS[j_][3]), \
+                                                    0, 1, 2, 3, 4, 5, 6, 7);                    \
+            acc[(ih) * 2 + i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_[i_], bq_, acc[(ih) * 2 + i_][j_], \
+                                                                                   0, 0, 0, sca, 0, scb); \
+        }
+#define G4P_MFMA_BEGIN() do { G4P_SB(); __builtin_amdgcn_s_setprio(1); } while (0)
+#define G4P_MFMA_END() do { __builtin_amdgcn_s_setprio(0); G4P_SB(); } while (0)
+
+    // one k-tile: tile t from LDS stage `cur` and register set bS; DMA of tile t + 2 into stage `nxt2`; reload of bS with
+    // tile t + 2 (base address b2)
+#define G4P_TILE(bS, t)                                                                         \
+    do {                                                                                        \
+        const unsigned char *const sa = smem_raw + cur * STB;                                   \
+        const int t2_ = (t) + 2 < nk ? (t) + 2 : nk - 1;                                        \
+        const unsigned char *const b2 = tB + (size_t)t2_ * bks;                                 \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NB + NA) : "memory");                      \
+        G4P_SB();                                                                               \
+        __builtin_amdgcn_s_barrier();                                                           \
+        G4P_SB();                                                                               \
+        dma_a(t2_, nxt2);                                                                       \
+        if constexpr (NSPLIT == 2) {                                                            \
+            /* fragments of the NEXT group are requested ahead of the last four MFMAs of the current one: hipcc forgets its */ \
+            /* lgkmcnt bookkeeping at every asm statement and waits lgkmcnt(0) behind it, which is free once they landed */ \
+            half8 h0[2], h1[2], g0[2], g1[2];                                                   \
+            v8i q0[2], q1[2];                                                                   \
+            G4P_RD_H(h0, sa, 0, 0, 0);                                                          \
+            G4P_RD_H(h1, sa, 0, 1, 0);                                                          \
+            G4P_WAIT2(INFL - 2, bS[0][0], bS[1][0]);                                            \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_F16(h0, 0, bS, 0);                                                              \
+            G4P_MFMA_END();                                                                     \
+            G4P_RD_Q(q0, sa, 0);                                                                \
+            G4P_RD_Q(q1, sa, 1);                                                                \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_F16(h1, 1, bS, 0);                                                              \
+            G4P_MFMA_END();                                                                     \
+            G4P_LDB_GROUP(bS, b2, 0);                                                           \
+            G4P_WAIT4(INFL - 4, bS[0][2], bS[0][3], bS[1][2], bS[1][3]);                        \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_F8(q0, 0, bS);                                                                  \
+            G4P_MFMA_END();                                                                     \
+            G4P_RD_H(g0, sa, 0, 0, 1);                                                          \
+            G4P_RD_H(g1, sa, 0, 1, 1);                                                          \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_F8(q1, 1, bS);                                                                  \
+            G4P_MFMA_END();                                                                     \
+            G4P_LDB_GROUP(bS, b2, 2);                                                           \
+            G4P_LDB_GROUP(bS, b2, 3);                                                           \
+            G4P_WAIT2(INFL - 2, bS[0][1], bS[1][1]);                                            \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_F16(g0, 0, bS, 1);                                                              \
+            G4P_F16(g1, 1, bS, 1);                                                              \
+            G4P_MFMA_END();                                                                     \
+            G4P_LDB_GROUP(bS, b2, 1);                                                           \
+        } else {                                                                                \
+            /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi */ \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                  \
+                half8 ah0[2], al0[2], ah1[2], al1[2];                                           \
+                G4P_RD_H(ah0, sa, 0, 0, ks);                                                    \
+                if (NSPLIT == 3) G4P_RD_H(al0, sa, 1, 0, ks);                                   \
+                if (NSPLIT == 3) {                                                              \
+                    if (ks == 0) G4P_WAIT4(INFL - 4, bS[0][0], bS[1][0], bS[0][2], bS[1][2]);   \
+                    else G4P_WAIT4(INFL - 4, bS[0][1], bS[1][1], bS[0][3], bS[1][3]);           \
+                } else {                                                                        \
+                    if (ks == 0) G4P_WAIT2(INFL - 2, bS[0][0], bS[1][0]);                       \
+                    else G4P_WAIT2(INFL - 2, bS[0][1], bS[1][1]);                               \
+                }                                                                               \
+                G4P_RD_H(ah1, sa, 0, 1, ks);                                                    \
+                if (NSPLIT == 3) G4P_RD_H(al1, sa, 1, 1, ks);                                   \
+                G4P_MFMA_BEGIN();                                                               \
+                if (NSPLIT == 3) {                                                              \
+                    G4P_F16(al0, 0, bS, ks);                                                    \
+                    G4P_F16(ah0, 0, bS, 2 + ks);                                                \
+                }                                                                               \
+                G4P_F16(ah0, 0, bS, ks);                                                        \
+                if (NSPLIT == 3) {                                                              \
+                    G4P_F16(al1, 1, bS, ks);                                                    \
+                    G4P_F16(ah1, 1, bS, 2 + ks);                                                \
+                }                                                                               \
+                G4P_F16(ah1, 1, bS, ks);                                                        \
+                G4P_MFMA_END();                                                                 \
+                if (ks == 0) {                                                                  \
+                    G4P_LDB_GROUP(bS, b2, 0);                                                   \
+                    if (NSPLIT == 3) G4P_LDB_GROUP(bS, b2, 2);                                  \
+                } else {                                                                        \
+                    G4P_LDB_GROUP(bS, b2, 1);                                                   \
+                    if (NSPLIT == 3) G4P_LDB_GROUP(bS, b2, 3);                                  \
+                }                                                                               \
+            }                                                                                   \
+        }                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+        { const int c_ = cur; cur = nxt1; nxt1 = nxt2; nxt2 = c_; }                             \
+    } while (0)
+
+    // ---- prologue: A(0) B(0) A(1) B(1) in the loop's issue order
+    int cur = 0, nxt1 = 1, nxt2 = 2;
+    {
+        const int t1 = nk > 1 ? 1 : 0;
+        const unsigned char *const b0 = tB, *const b1 = tB + (size_t)t1 * bks;
+        dma_a(0, 0);
+        if constexpr (NSPLIT == 2) {
+            G4P_LDB_GROUP(bE, b0, 0); G4P_LDB_GROUP(bE, b0, 2); G4P_LDB_GROUP(bE, b0, 3); G4P_LDB_GROUP(bE, b0, 1);
+        } else {
+            G4P_LDB_GROUP(bE, b0, 0); if (NSPLIT == 3) G4P_LDB_GROUP(bE, b0, 2);
+            G4P_LDB_GROUP(bE, b0, 1); if (NSPLIT == 3) G4P_LDB_GROUP(bE, b0, 3);
+        }
+        dma_a(t1, 1);
+        if constexpr (NSPLIT == 2) {
+            G4P_LDB_GROUP(bO, b1, 0); G4P_LDB_GROUP(bO, b1, 2); G4P_LDB_GROUP(bO, b1, 3); G4P_LDB_GROUP(bO, b1, 1);
+        } else {
+            G4P_LDB_GROUP(bO, b1, 0); if (NSPLIT == 3) G4P_LDB_GROUP(bO, b1, 2);
+            G4P_LDB_GROUP(bO, b1, 1); if (NSPLIT == 3) G4P_LDB_GROUP(bO, b1, 3);
+        }
+    }
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < nk; t += 2) {
+        G4P_TILE(bE, t);
+        G4P_TILE(bO, t + 1);
+    }
+    if (t < nk) G4P_TILE(bE, t);
+    // drain the look-ahead loads (they target registers and LDS stages that are dead, but must have landed before reuse)
+    if constexpr (NSPLIT == 1)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bE[0][0]), "+v"(bE[1][0]), "+v"(bE[0][1]), "+v"(bE[1][1]),
+                       "+v"(bO[0][0]), "+v"(bO[1][0]), "+v"(bO[0][1]), "+v"(bO[1][1]) :: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bE[0][0]), "+v"(bE[1][0]), "+v"(bE[0][1]), "+v"(bE[1][1]),
+                       "+v"(bE[0][2]), "+v"(bE[1][2]), "+v"(bE[0][3]), "+v"(bE[1][3]),
+                       "+v"(bO[0][0]), "+v"(bO[1][0]), "+v"(bO[0][1]), "+v"(bO[1][1]),
+                       "+v"(bO[0][2]), "+v"(bO[1][2]), "+v"(bO[0][3]), "+v"(bO[1][3]) :: "memory");
+    G4P_SB();
+#undef G4P_TILE
+#undef G4P_LDB
+#undef G4P_LDB_GROUP
+#undef G4P_WAIT2
+#undef G4P_WAIT4
+#undef G4P_RD_H
+#undef G4P_RD_Q
+#undef G4P_F16
+#undef G4P_F8
+#undef G4P_MFMA_BEGIN
+#undef G4P_MFMA_END
+#undef G4P_SB
+
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    gemm_epilogue<EPI>(p, acc, m0, n0 + wid * 64, lane_e);
 }
 
 // ======================================================================================
@@ -1278,9 +1598,28 @@ hipError_t launch_gemm_ns(const xb::GemmParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
+template <int EPI, int NSPLIT>
+hipError_t launch_gemm4p_ns(const xb::GemmParams &p, hipStream_t stream)
+{
+    const int MT = (p.M + G4_BM - 1) / G4_BM, NT = (p.Nn + G4_BN - 1) / G4_BN;
+    const int SN = NT < 4 ? NT : 4, SM = 64 / SN;
+    const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see gemm4_tile_origin
+    dim3 grid(8 * 64 * ((supers + 7) / 8)), block(G4_THREADS);
+    const size_t lds = (size_t)3 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;       // [3 stages][parts][128 rows x 64 B]
+    hipLaunchKernelGGL((gemm4p_kernel<EPI, NSPLIT>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
 {
+    if (p.b4) {
+        switch (p.nsplit) {
+        case 1: return launch_gemm4p_ns<EPI, 1>(p, stream);
+        case 2: return launch_gemm4p_ns<EPI, 2>(p, stream);
+        default: return launch_gemm4p_ns<EPI, 3>(p, stream);
+        }
+    }
     switch (p.nsplit) {
     case 1: return launch_gemm_ns<EPI, 1>(p, stream);
     case 2: return launch_gemm_ns<EPI, 2>(p, stream);

@@ -30,6 +30,27 @@ struct DecodeParams {
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream);
 int decode_lanes_per_state(int S, int N);   // 1, 2 or 4 lanes serve one CRF state (env XB_DECODE_LPS overrides for tests)
 
+// ---------------------------------------------------------------- CTC-CRF loss scans (xb_decode.hip)
+// seqdist.ctc_simple logZ over the stay / move lattice of the targets (crf/model.py:102-135): position l of n = Lt - sl + 1,
+// stay[t][l] = scores[t][b][stay_idx[b][l]], move[t][l] = scores[t][b][move_idx[b][l]] (l -> l + 1).
+struct CtcParams {
+    const float *scores;         // (T, N, C) fp32 with the blank column
+    int T, N, C;
+    const int32_t *stay_idx;     // (N, n)
+    const int32_t *move_idx;     // (N, n - 1)
+    int n;
+    const int32_t *tlen;         // (N) target lengths (in bases); positions in use = tlen + 1 - sl
+    int sl;
+    int semiring;                // 0 Log, 1 Max
+    float *alpha;                // (N, T + 1, n) workspace, required for gstay / gmove
+    float *logz;                 // (N) or nullptr
+    float *gstay;                // (T, N, n) or nullptr: Log: d logZ / d stay; Max: the one-hot alignment (zeroed by the caller)
+    float *gmove;                // (T, N, n - 1) or nullptr (Log only)
+    unsigned *error;             // bit 1 set when a target length is out of range
+};
+hipError_t launch_ctc_scan(const CtcParams &p, hipStream_t stream);
+int ctc_max_positions();
+
 // ---------------------------------------------------------------- encoder (xb_encoder.hip)
 
 // conv1(1->4,k5,p2)+SiLU, conv2(4->16,k5,p2)+SiLU, then the im2col rows of conv3
@@ -68,7 +89,16 @@ struct GemmParams {
     int a_exp, b_exp;            // nsplit == 2: exponents of the A and B q8 images
     int out_exp;                 // nsplit == 2, EPI_SILU_SPLIT: exponent of the q8 image written to out_lo
     int gin_n;                   // EPI_BIAS_F32: > 0 selects the member-major gin layout (below) with gin_n chunks per time step
+    // gemm4p_kernel (two workgroups per CU, B straight from a fragment-major weight image, see xb_encoder.hip): used when b4
+    // is set; otherwise gemm8r_kernel (one 256 x 256 workgroup per CU, both operands through LDS; kept as the A/B reference)
+    const unsigned char *b4;     // [K / 32][rows4 / 32][pieces][64 lanes][16 B], rows4 = Nn rounded up to 256 (zero rows)
+    size_t b4_kstride;           // bytes between consecutive k-tiles of b4 = rows4 / 32 * pieces * 1024
 };
+// pieces per 32-row block and k-tile of the fragment-major image for a given nsplit (lane l = 32 h + r holds row r):
+//   piece 0, 1: the 8 fp16 `hi` values of columns 32 kt + 16 ks + 8 h .. + 8, ks = 0, 1
+//   nsplit 3: piece 2, 3: the same of `lo`;   nsplit 2: pieces 2, 3 = bytes 0..15 / 16..31 of the q8 half the B role reads
+//   (h = 0: the l8 codes of the 32 columns, h = 1: the h8 codes)
+inline int gemm4_pieces(int nsplit) { return nsplit == 1 ? 2 : 4; }
 // gin layout (input projection of an LSTM layer, written by the GEMM, read by lstm_kernel): row m = t * n + chunk, column
 // c = unit * 4 + gate.  Stored member-major, [t][c / 128][chunk][c % 128]: the 64 chunks x 128 gate columns a recurrence
 // workgroup (32 units) needs per step are ONE contiguous 32 KiB block instead of 64 segments 4F floats apart.

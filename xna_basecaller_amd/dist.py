@@ -11,8 +11,15 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier",
+__all__ = ["init_from_env", "env_rank_world", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier",
            "DeferredGather"]
+
+
+def env_rank_world():
+    """(rank, world) from torchrun's environment WITHOUT touching torch.distributed or the GPU -- for work that has to
+    happen before the device is initialised (forking the reader pool)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return (int(os.environ.get("RANK", "0")), world) if world > 1 else (0, 1)
 
 
 def init_from_env(backend=None):

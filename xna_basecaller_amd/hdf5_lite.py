@@ -14,11 +14,18 @@ Implemented from the HDF5 File Format Specification (version 3.0), the parts fas
   * filter pipeline (message versions 1 and 2): deflate (1), shuffle (2), fletcher32 (3) and ONT's VBZ (32020).
 
 VBZ (github.com/nanoporetech/vbz_compression, the HDF5 filter registered as 32020; cd_values = [version, integer size,
-zig-zag flag, zstd level]): a chunk is a 4-byte little-endian uncompressed byte count followed by, when the zstd level is
-non-zero, one zstd frame; inside it the samples are StreamVByte-coded.  16-bit samples use the "svb16" layout: ceil(n/8)
-key bytes (one bit per value, least significant bit first: 0 = one data byte, 1 = two little-endian data bytes), then the
-data bytes; the values are zig-zag coded differences to the previous sample (first sample against 0).  32-bit samples
-use classic StreamVByte (two key bits per value).  zstd itself comes from the system's libzstd through ctypes.
+delta + zig-zag flag, zstd level]): a chunk is a 4-byte little-endian uncompressed byte count followed by, when the zstd
+level is non-zero, one zstd frame; inside it the samples are StreamVByte-coded, and the layout depends on the VERSION:
+  * version 0 (what ont_fast5_api writes: VBZ = (32020, (0, 2, 1, 1)), and MinKNOW): samples of 1, 2 or 4 bytes are widened
+    to 32 bits, replaced by the zig-zag code of their difference to the previous sample (first against 0) when the flag is
+    set, and coded with CLASSIC StreamVByte: ceil(n/4) key bytes, two bits per value (bytes - 1, first value in the low
+    bits), then the little-endian data bytes.
+  * version 1: 1-byte samples are stored raw; 2-byte samples use "svb16": ceil(n/8) key bytes, one bit per value (least
+    significant bit first: 0 = one data byte, 1 = two), differences and zig-zag in 16-bit arithmetic; 4-byte samples use
+    the 0/1/2/4-byte StreamVByte variant (key code 0 = no data byte, 3 = four).
+Restated from the published sources from memory -- no file written by ONT's own encoder exists in this image, so the
+version-0 path is pinned by a hand-computed vector from the StreamVByte format description (tests/test_host.py), not by
+a MinKNOW file.  zstd itself comes from the system's libzstd through ctypes.
 """
 import ctypes
 import ctypes.util
@@ -98,19 +105,32 @@ def _svb16_decode(buf, count):
     return lo | (hi << 8)
 
 
-def _svb32_decode(buf, count):
-    """classic StreamVByte: 2 key bits per value (length - 1), four values per key byte, then the data bytes."""
+def _svb32_decode(buf, count, lengths=(1, 2, 3, 4)):
+    """StreamVByte: 2 key bits per value, four values per key byte (first value in the low bits), then the data bytes.
+    `lengths` maps a key code to its byte count: (1, 2, 3, 4) classic, (0, 1, 2, 4) the 0124 variant."""
     nkey = (count + 3) // 4
+    if len(buf) < nkey:
+        raise Hdf5Error("vbz: truncated StreamVByte keys")
     kb = np.frombuffer(buf, dtype=np.uint8, count=nkey)
     codes = np.stack([(kb >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)[:count].astype(np.int64)
+    nbytes = np.asarray(lengths, dtype=np.int64)[codes]
     data = np.frombuffer(buf, dtype=np.uint8, offset=nkey)
-    starts = np.concatenate(([0], np.cumsum(1 + codes)[:-1])) if count else np.zeros(0, np.int64)
+    starts = np.concatenate(([0], np.cumsum(nbytes)[:-1])) if count else np.zeros(0, np.int64)
+    if count and starts[-1] + nbytes[-1] > data.size:
+        raise Hdf5Error("vbz: truncated StreamVByte data")
     out = np.zeros(count, dtype=np.uint32)
     for b in range(4):
-        take = codes >= b
+        take = nbytes > b
         idx = np.minimum(starts + b, max(data.size - 1, 0))
         out |= np.where(take, data[idx].astype(np.uint32) << (8 * b), 0).astype(np.uint32)
     return out
+
+
+def _unzigzag_cumsum(v, dtype):
+    """zig-zag codes of differences -> samples, in `dtype`'s modular arithmetic"""
+    v = v.astype(dtype)
+    v = ((v >> 1) ^ (0 - (v & 1))).astype(dtype)
+    return np.cumsum(v, dtype=dtype)
 
 
 def vbz_decode(chunk, cd_values):
@@ -118,28 +138,35 @@ def vbz_decode(chunk, cd_values):
     version, int_size, zigzag, level = (list(cd_values) + [0, 0, 0, 0])[:4]
     if version not in (0, 1):
         raise Hdf5Error("vbz: unsupported version %d" % version)
+    if len(chunk) < 4:
+        raise Hdf5Error("vbz: short chunk")
     (size,) = struct.unpack_from("<I", chunk, 0)
     body = bytes(chunk[4:])
     if level:
-        body = zstd_decompress(body, size + size // 2 + 64)
-    if int_size in (0, 1):
+        body = zstd_decompress(body, 5 * size // max(int_size, 1) + size + 64)
+    if int_size == 0 or (int_size == 1 and version == 1):
         if len(body) < size:
             raise Hdf5Error("vbz: short chunk")
         return body[:size]
+    if int_size not in (1, 2, 4):
+        raise Hdf5Error("vbz: unsupported integer size %d" % int_size)
     count = size // int_size
+    out_dtype = {1: "u1", 2: "<u2", 4: "<u4"}[int_size]
+    if version == 0:
+        # widened to 32 bits, classic StreamVByte; differences and zig-zag in 32-bit arithmetic, then cast back
+        v = _svb32_decode(body, count)
+        if zigzag:
+            v = _unzigzag_cumsum(v, np.uint32)
+        return v.astype(out_dtype).tobytes()
     if int_size == 2:
         v = _svb16_decode(body, count)
         if zigzag:
-            v = ((v >> 1) ^ (0 - (v & 1))).astype(np.uint16)          # zig-zag decode
-            v = np.cumsum(v.astype(np.uint16), dtype=np.uint16)        # differences -> samples (wraps mod 2^16)
-        return v.astype("<u2").tobytes()
-    if int_size == 4:
-        v = _svb32_decode(body, count)
-        if zigzag:
-            v = ((v >> 1) ^ (0 - (v & 1))).astype(np.uint32)
-            v = np.cumsum(v.astype(np.uint32), dtype=np.uint32)
-        return v.astype("<u4").tobytes()
-    raise Hdf5Error("vbz: unsupported integer size %d" % int_size)
+            v = _unzigzag_cumsum(v, np.uint16)
+        return v.astype(out_dtype).tobytes()
+    v = _svb32_decode(body, count, lengths=(0, 1, 2, 4))
+    if zigzag:
+        v = _unzigzag_cumsum(v, np.uint32)
+    return v.astype(out_dtype).tobytes()
 
 
 def _svb16_encode(values):
@@ -154,13 +181,39 @@ def _svb16_encode(values):
     return keys + out[:total].tobytes()
 
 
-def vbz_encode_int16(samples, level=1):
-    """The writer side for 16-bit samples with delta + zig-zag (used by the tests to build synthetic fast5 files)."""
-    x = np.asarray(samples, dtype="<i2").view(np.uint16)
-    d = np.diff(np.concatenate(([np.uint16(0)], x)).astype(np.uint16)).astype(np.uint16)      # wraps mod 2^16
-    s = d.view(np.int16).astype(np.int32)
-    z = ((s << 1) ^ (s >> 15)).astype(np.uint16)
-    body = _svb16_encode(z)
+def _svb32_encode(values):
+    """classic StreamVByte of 32-bit values (the shortest of 1..4 bytes each)"""
+    v = np.asarray(values, dtype=np.uint32)
+    nbytes = 1 + (v > 0xFF).astype(np.int64) + (v > 0xFFFF) + (v > 0xFFFFFF)
+    codes = (nbytes - 1).astype(np.uint8)
+    pad = (-v.size) % 4
+    c4 = np.concatenate((codes, np.zeros(pad, np.uint8))).reshape(-1, 4)
+    keys = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8).tobytes()
+    starts = np.concatenate(([0], np.cumsum(nbytes)[:-1])) if v.size else np.zeros(0, np.int64)
+    out = np.zeros(int(nbytes.sum()), dtype=np.uint8)
+    for b in range(4):
+        take = nbytes > b
+        out[starts[take] + b] = ((v[take] >> (8 * b)) & 0xFF).astype(np.uint8)
+    return keys + out.tobytes()
+
+
+def vbz_encode_int16(samples, level=1, version=0):
+    """The writer side for 16-bit samples with delta + zig-zag (used by the tests to build synthetic fast5 files).
+    version 0 = what ont_fast5_api / MinKNOW write (32-bit classic StreamVByte), version 1 = svb16."""
+    x = np.asarray(samples, dtype="<i2")
+    if version == 0:
+        w = x.astype(np.int64)
+        d = np.diff(np.concatenate(([0], w)))                                   # fits 32 bits: |d| < 2^17
+        z = ((d << 1) ^ (d >> 63)).astype(np.uint32)
+        body = _svb32_encode(z)
+    elif version == 1:
+        u = x.view(np.uint16)
+        d = np.diff(np.concatenate(([np.uint16(0)], u)).astype(np.uint16)).astype(np.uint16)      # wraps mod 2^16
+        s16 = d.view(np.int16).astype(np.int32)
+        z = ((s16 << 1) ^ (s16 >> 15)).astype(np.uint16)
+        body = _svb16_encode(z)
+    else:
+        raise Hdf5Error("vbz: unsupported version %d" % version)
     if level:
         body = zstd_compress(body, level)
     return struct.pack("<I", x.size * 2) + body

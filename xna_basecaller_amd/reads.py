@@ -278,12 +278,14 @@ def read_jobs(directory, read_ids=None, skip=False, recursive=False):
 class ReadLoader:
     """
     Iterator over the selected reads of a directory.  The worker pool is started in the constructor -- create it before
-    the GPU is initialised (forking a process that holds a HIP context is best avoided) -- and stays up to a few reads
-    ahead of the consumer; results arrive in job order.
+    the GPU is initialised (forking a process that holds a HIP context is best avoided).  Results arrive in job order,
+    and the pool stays at most `lookahead` reads (default 4 per worker) ahead of the consumer: jobs are handed out one
+    by one as results are taken, so a slow device stage bounds the prepared signals held in host memory (Pool.imap alone
+    has no backpressure; the reference calls it once per file, fast5.py:284-296, which caps its backlog at one file).
     """
 
     def __init__(self, directory, read_ids=None, skip=False, n_proc=1, recursive=False, cancel=None, shard=None,
-                 limit=0):
+                 limit=0, lookahead=0):
         jobs = list(enumerate(read_jobs(directory, read_ids=read_ids, skip=skip, recursive=recursive)))
         if limit:
             jobs = jobs[:limit]
@@ -292,18 +294,29 @@ class ReadLoader:
             rank, world = shard
             jobs = [(i, j) for i, j in jobs if i % world == rank]
         self.jobs, self.cancel, self.pool = jobs, cancel, None
+        self.lookahead = max(1, int(lookahead)) if lookahead else 4 * max(1, n_proc)
+        self.max_pending = 0                        # high-water mark of reads in flight or waiting (tests)
         if n_proc > 1 and len(jobs) > 1:
             import multiprocessing as mp
             self.pool = mp.get_context("fork" if "fork" in mp.get_all_start_methods() else None).Pool(min(n_proc, len(jobs)))
-            self._results = self.pool.imap(_load_read, [j for _, j in jobs], chunksize=1)
 
     def __len__(self):
         return len(self.jobs)
 
     def __iter__(self):
+        from collections import deque
+        pending, nxt = deque(), 0
         try:
             for k, (i, job) in enumerate(self.jobs):
-                read = next(self._results) if self.pool is not None else _load_read(job)
+                if self.pool is not None:
+                    # top the window up, then take the oldest result: at most `lookahead` reads are ever outstanding
+                    while nxt < len(self.jobs) and len(pending) < self.lookahead:
+                        pending.append(self.pool.apply_async(_load_read, (self.jobs[nxt][1],)))
+                        nxt += 1
+                    self.max_pending = max(self.max_pending, len(pending))
+                    read = pending.popleft().get()
+                else:
+                    read = _load_read(job)
                 read.index = i
                 yield read
                 if self.cancel is not None and self.cancel.is_set():
