@@ -13,8 +13,8 @@ that is already resident in HBM.  Default workload = BASELINE.json configs[2]: t
          --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; every rank basecalls its own batch (reads shard, weak scaling) and the
-called sequences are gathered with ONE all_gather per step over RCCL (the path's only exchange), issued
-on a side stream one step late behind an event, so that N = 1 and N > 1 time the same device pipeline.
+called sequences are gathered with ONE all-gather per step over RCCL (the path's only exchange: xb_gather_called of the C
+ABI, on the communicator's own stream behind an event), so that N = 1 and N > 1 time the same device pipeline.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--lstm-mode", type=int, default=0)
+    ap.add_argument("--gather", default="xb", choices=["xb", "torch"],
+                    help="N > 1: xb = xb_gather_called over librccl (C ABI); torch = torch.distributed all_gather")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the deferred side-stream gather plumbing even with one rank (harness self-test)")
     args = ap.parse_args()
@@ -121,24 +123,46 @@ def main():
     # two output buffer sets in rotation: batch k's sequences are gathered (side stream) while batch k+1 computes
     d_seq = [torch.empty((N, T), dtype=torch.int8, device=dev) for _ in range(2)]
     d_len = [torch.empty((N,), dtype=torch.int32, device=dev) for _ in range(2)]
-    gather = xdist.DeferredGather() if (world > 1 or args.force_gather) else None
+    # The path's one exchange: the gather of called sequences, through the C ABI (xb_comm: RCCL all-gathers on
+    # the communicator's own stream behind the context's result stream).  --gather torch keeps the torch.distributed route
+    # (the same RCCL underneath) and is also the fallback should the communicator not come up.
+    gather, gather_kind = None, "none"
+    if world > 1 or args.force_gather:
+        if args.gather == "xb":
+            try:
+                gather, gather_kind = xdist.RcclGather(ctx, local, rank, world), "xb_gather_called (librccl via the C ABI)"
+            except Exception as e:                                   # noqa: BLE001 -- reported, then the torch route
+                sys.stderr.write("rank %d: xb_comm unavailable (%s); gathering through torch.distributed\n" % (rank, e))
+        if world > 1 and args.gather == "xb":                        # all ranks take the same route
+            import torch.distributed as tdist
+            agree = torch.tensor([1 if gather is not None else 0], dtype=torch.int32, device=dev)
+            tdist.all_reduce(agree, op=tdist.ReduceOp.MIN)
+            if int(agree.item()) == 0 and gather is not None:
+                gather.close()
+                gather = None
+        if gather is None:
+            gather, gather_kind = xdist.DeferredGather(), "torch.distributed all_gather (nccl backend = RCCL)"
+    use_xb = isinstance(gather, xdist.RcclGather)
     state = {"k": 0}
 
     def step():
         k = state["k"]
         state["k"] = k + 1
         b = k & 1
-        if gather is not None:
+        if use_xb:
+            gather.before_batch()                                # the gather that last read buffer set b is done (device-side)
+        elif gather is not None:
             out_stream = torch.cuda.ExternalStream(ctx.result_stream(), device=dev)
             ev = gather.consumed(k - 2)                      # the gather that last read this buffer set
             if ev is not None:
                 out_stream.wait_event(ev)
         ctx.basecall_chunks_dev(d_signal.data_ptr(), N, alphabet, d_seq[b].data_ptr(), d_len[b].data_ptr())
-        if gather is not None:
+        if use_xb:
+            gather.submit(d_seq[b], d_len[b])                    # starts on the device when batch k is complete
+        elif gather is not None:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.ExternalStream(ctx.result_stream(), device=dev))
             gather.submit(d_seq[b], d_len[b], ready)         # starts the gather of batch k-1
-            return
 
     def fence():
         if gather is not None:
@@ -215,7 +239,7 @@ def main():
                                % ({(5, 512): "1", (6, 512): "2", (6, 1024): "3] per-GPU workload [1 of 8 ranks",
                                    (6, 2048): "4] per-GPU workload [1 of 8 ranks"}.get((nb, N), "-"), nb, S, S * E, L, N, F),
                    "n_base": nb, "chunksize": L, "batch_per_gpu": N, "T": T, "parallelism": "reads sharded x%d" % world,
-                   "collective": "all_gather of packed sequences per step, on a side stream one step late" if world > 1 else "none"},
+                   "collective": ("all_gather of packed sequences per step on a side stream: " + gather_kind) if gather is not None else "none"},
         "roofline": roofline, "roofline_decode": roofline_decode,
         "stage_ms_per_step": {k: v[0] / K for k, v in stages.items()},
         "stage_note": "HIP-event time per stage on its own stream; lstm_in / linear run slab by slab on a second stream "

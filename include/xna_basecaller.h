@@ -146,6 +146,25 @@ XB_API int xb_crf_scans_dev(xb_ctx *ctx, const float *d_scores, int T, int n, in
 XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz);
 XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz);
 
+/*
+ * The CTC-CRF loss scans (CTC_CRF.ctc_loss and ctc_viterbi_alignments, crf/model.py:102-135: prepare_ctc_scores +
+ * seqdist.ctc_simple.logZ_cupy / viterbi_alignments), for `bonito evaluate` / fine-tuning on the same device:
+ *   scores  (T, n, S*(n_base+1)) fp32 with the blank column -- ctc_loss passes the NORMALISED scores
+ *           (scores - xb_crf_logz / T, crf/model.py:48-49,120-121); targets (n, Lt) int32 CTC labels (1..n_base, 0 = padding);
+ *           target_lengths (n) in bases, state_len <= length <= Lt.  With np = Lt - state_len + 1 target positions the lattice
+ *           has a stay edge per position (score column stay_idx) and a move edge between consecutive positions (move_idx).
+ *   xb_ctc_logz:  logz (n) = log-sum over all monotone paths that end at position target_length - state_len at time T
+ *           (loss = -logz / target_length);  gstay (T, n, np) / gmove (T, n, np-1) [optional] = d logz / d stay, d logz / d move,
+ *           the restricted posteriors -- scatter-added over (stay_idx, move_idx) they are d logz / d scores.
+ *   xb_ctc_alignments:  the Max-semiring path: alignments (T, n, np) one-hot over positions (where the best path sits before
+ *           step t: seqdist's stay.grad + shifted move.grad; ties prefer the stay edge), max_score (n) [optional].
+ * Same arithmetic contract as the decode (bit-equal to the oracle; seqdist itself is absent: "parity unpinned").
+ */
+XB_API int xb_ctc_logz(xb_ctx *ctx, const float *scores, int T, int n, const int32_t *targets, int Lt,
+                       const int32_t *target_lengths, float *logz, float *gstay, float *gmove);
+XB_API int xb_ctc_alignments(xb_ctx *ctx, const float *scores, int T, int n, const int32_t *targets, int Lt,
+                             const int32_t *target_lengths, float *alignments, float *max_score);
+
 /* compute_scores (crf/basecall.py:27-82), viterbi branch: encode + decode without materialising
  * the blank column or copying scores off the device. */
 XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet,
@@ -176,6 +195,38 @@ XB_API int xb_synchronize(xb_ctx *ctx);
  * counterpart.
  */
 XB_API void *xb_result_stream(xb_ctx *ctx);
+
+/* ---- multi-GPU: the gather of called sequences --------------------------------------------------
+ *
+ * Reads shard over the GPUs of a node, one process and one xb_ctx per GPU, with no data-path collective; the only exchange
+ * is this gather of the packed sequences (RCCL over xGMI; librccl is opened at run time).  The reference is single-device
+ * Python and has no counterpart.
+ *   xb_comm_unique_id   rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band (the
+ *                       launcher's rendezvous: xna_basecaller_amd/dist.py exchanges it over a socket on MASTER_ADDR);
+ *   xb_comm_create      every rank joins (ncclCommInitRank) on its device; collective: returns when all `world` ranks have;
+ *   xb_gather_called    all-gather of one batch: d_seq (n, T) int8 / d_seq_len (n) int32 of this rank into
+ *                       d_all_seq (world, n, T) / d_all_len (world, n) on every rank, enqueued on the communicator's own stream
+ *                       behind xb_result_stream(ctx) (ctx may be NULL when the caller has synchronised) -- returns at once;
+ *                       every rank passes the same n and T;
+ *   xb_comm_fence       makes the streams of ctx wait (on the device) for the gather issued `lag` calls ago (0: the latest, 1: the
+ *                       one before it) and everything older -- call it before output buffers a gather still reads are handed
+ *                       to a later xb_basecall_chunks_dev (two buffer sets in rotation: lag 1 right before enqueueing a batch);
+ *   xb_comm_synchronize host-side completion of the gathers issued so far.
+ */
+#define XB_COMM_ID_BYTES 128
+typedef struct xb_comm xb_comm;
+XB_API int xb_comm_unique_id(char id[XB_COMM_ID_BYTES]);
+XB_API int xb_comm_create(xb_comm **out, int device, int rank, int world, const char id[XB_COMM_ID_BYTES]);
+XB_API void xb_comm_destroy(xb_comm *comm);
+XB_API int xb_comm_rank(const xb_comm *comm);
+XB_API int xb_comm_world(const xb_comm *comm);
+XB_API const char *xb_comm_last_error(const xb_comm *comm);
+XB_API int xb_gather_called(xb_comm *comm, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_seq_len, int n, int T,
+                            int8_t *d_all_seq, int32_t *d_all_len);
+XB_API int xb_comm_fence(xb_comm *comm, xb_ctx *ctx, int lag);
+XB_API int xb_comm_synchronize(xb_comm *comm);
+/* Makes every stream of ctx wait for `hip_event` (a hipEvent_t passed as void *) -- the edge xb_comm_fence uses. */
+XB_API int xb_stream_wait_event(xb_ctx *ctx, void *hip_event);
 
 /* ---- introspection / measurement ---------------------------------------------------------- */
 

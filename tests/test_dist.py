@@ -119,3 +119,26 @@ def test_single_process_paths():
     assert xd.rank() == 0 and xd.world_size() == 1
     assert list(xd.shard("abc")) == [(0, "a"), (1, "b"), (2, "c")]
     assert xd.gather_called([(2, "b", "A", "O"), (0, "a", "C", "O")]) == [(0, "a", "C", "O"), (2, "b", "A", "O")]
+
+
+def _id_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from xna_basecaller_amd import dist as xdist
+    cid = xdist.exchange_comm_id(rank, world, lambda: bytes(range(128)))
+    q.put((rank, cid))
+
+
+def test_comm_id_rendezvous_without_torch_distributed():
+    """The 128-byte communicator id of xb_comm_create travels from rank 0 to the other ranks over a one-shot TCP rendezvous
+    on MASTER_ADDR : MASTER_PORT + 1 when no torch.distributed process group exists (a pure C-ABI launcher's route)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_id_worker, args=(r, 3, port, q)) for r in (2, 1, 0)]          # rank 0 comes up LAST
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}

@@ -21,8 +21,11 @@ EXPORTS = [
     "xb_weights_ready", "xb_encode", "xb_encode_dev", "xb_decode", "xb_decode_dev", "xb_crf_logz", "xb_crf_logz_dev", "xb_crf_scans", "xb_crf_scans_dev",
     "xb_basecall_chunks", "xb_basecall_chunks_dev", "xb_synchronize", "xb_set_profiling",
     "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
-    "xb_submit_chunks", "xb_collect_chunks",
+    "xb_submit_chunks", "xb_collect_chunks", "xb_ctc_logz", "xb_ctc_alignments",
+    "xb_comm_unique_id", "xb_comm_create", "xb_comm_destroy", "xb_comm_rank", "xb_comm_world", "xb_comm_last_error",
+    "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event",
 ]
+XB_COMM_ID_BYTES = 128
 
 
 class XbConfig(C.Structure):
@@ -75,6 +78,20 @@ def load():
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
+    lib.xb_comm_unique_id.argtypes = [C.c_char_p]
+    lib.xb_comm_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.c_char_p]
+    lib.xb_comm_destroy.argtypes = [vp]
+    lib.xb_comm_destroy.restype = None
+    lib.xb_comm_rank.argtypes = [vp]
+    lib.xb_comm_world.argtypes = [vp]
+    lib.xb_comm_last_error.argtypes = [vp]
+    lib.xb_comm_last_error.restype = C.c_char_p
+    lib.xb_gather_called.argtypes = [vp, vp, vp, vp, ip, ip, vp, vp]
+    lib.xb_comm_fence.argtypes = [vp, vp, ip]
+    lib.xb_comm_synchronize.argtypes = [vp]
+    lib.xb_stream_wait_event.argtypes = [vp, vp]
+    lib.xb_ctc_logz.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp, vp]
+    lib.xb_ctc_alignments.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp]
     lib.xb_submit_chunks.argtypes = [vp, ip, vp, ip, C.c_char_p]
     lib.xb_collect_chunks.argtypes = [vp, ip, vp, vp]
     lib.xb_result_stream.argtypes = [vp]
@@ -197,6 +214,41 @@ class Context:
                                           _ptr(out.get("beta")), _ptr(out.get("logz")), _ptr(out.get("post"))))
         return out
 
+    def ctc_logz(self, scores, targets, target_lengths, want_grads=False):
+        """xb_ctc_logz: scores (T, n, C_blank), targets (n, Lt) CTC labels, target_lengths (n) -> {'logz': (n,)} and, with
+        want_grads, 'stay' (T, n, np) / 'move' (T, n, np - 1), np = Lt - state_len + 1 (the restricted posteriors)."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        targets = np.ascontiguousarray(targets, dtype=np.int32)
+        tl = np.ascontiguousarray(target_lengths, dtype=np.int32)
+        T, n, Cin = scores.shape
+        if Cin != self.C_blank or targets.shape[0] != n or tl.shape != (n,):
+            raise ValueError("ctc_logz: scores (T, n, %d), targets (n, Lt), target_lengths (n) expected" % self.C_blank)
+        Lt = targets.shape[1]
+        npos = Lt - (self.cfg.state_len - 1)
+        out = {"logz": np.empty((n,), np.float32)}
+        if want_grads:
+            out["stay"] = np.empty((T, n, max(npos, 0)), np.float32)
+            out["move"] = np.empty((T, n, max(npos - 1, 0)), np.float32)
+        self._check(self.lib.xb_ctc_logz(self.h, scores.ctypes.data, T, n, targets.ctypes.data, Lt, tl.ctypes.data,
+                                         out["logz"].ctypes.data, _ptr(out.get("stay")), _ptr(out.get("move"))))
+        return out
+
+    def ctc_alignments(self, scores, targets, target_lengths):
+        """xb_ctc_alignments: (alignments (T, n, np) one-hot over target positions, max path score (n,))."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        targets = np.ascontiguousarray(targets, dtype=np.int32)
+        tl = np.ascontiguousarray(target_lengths, dtype=np.int32)
+        T, n, Cin = scores.shape
+        if Cin != self.C_blank or targets.shape[0] != n or tl.shape != (n,):
+            raise ValueError("ctc_alignments: scores (T, n, %d), targets (n, Lt), target_lengths (n) expected" % self.C_blank)
+        Lt = targets.shape[1]
+        npos = Lt - (self.cfg.state_len - 1)
+        al = np.empty((T, n, max(npos, 0)), np.float32)
+        best = np.empty((n,), np.float32)
+        self._check(self.lib.xb_ctc_alignments(self.h, scores.ctypes.data, T, n, targets.ctypes.data, Lt, tl.ctypes.data,
+                                               al.ctypes.data, best.ctypes.data))
+        return al, best
+
     def crf_scans_dev(self, d_scores, T, n, has_blank, d_alpha=None, d_beta=None, d_logz=None, d_post=None):
         self._check(self.lib.xb_crf_scans_dev(self.h, _ptr(d_scores), T, n, int(bool(has_blank)), _ptr(d_alpha), _ptr(d_beta),
                                               _ptr(d_logz), _ptr(d_post)))
@@ -257,3 +309,53 @@ class Context:
         ln = (C.c_int64 * 5)()
         self._check(self.lib.xb_get_stage_times(self.h, ms, ln))
         return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(XB_STAGE_NAMES)}
+
+
+class Comm:
+    """xb_comm: the RCCL communicator of the path's one collective (include/xna_basecaller.h, 'multi-GPU').  Rank 0 draws
+    the id with Comm.unique_id() and passes it to the other ranks out of band (dist.exchange_comm_id)."""
+
+    def __init__(self, device, rank, world, comm_id):
+        self.lib = load()
+        if len(comm_id) != XB_COMM_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % XB_COMM_ID_BYTES)
+        h = C.c_void_p()
+        rc = self.lib.xb_comm_create(C.byref(h), int(device), int(rank), int(world), bytes(comm_id))
+        if rc:
+            raise XbError(rc, (self.lib.xb_comm_last_error(None) or b"").decode())
+        self.h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        buf = C.create_string_buffer(XB_COMM_ID_BYTES)
+        rc = lib.xb_comm_unique_id(buf)
+        if rc:
+            raise XbError(rc, (lib.xb_comm_last_error(None) or b"").decode())
+        return buf.raw
+
+    def _check(self, rc):
+        if rc:
+            raise XbError(rc, (self.lib.xb_comm_last_error(self.h) or b"").decode())
+
+    def gather_called(self, ctx, d_seq, d_len, n, T, d_all_seq, d_all_len):
+        """All-gather of one batch on the communicator's stream, behind ctx's result stream (device pointers as ints)."""
+        self._check(self.lib.xb_gather_called(self.h, ctx.h if ctx is not None else None, _ptr(d_seq), _ptr(d_len), int(n), int(T),
+                                              _ptr(d_all_seq), _ptr(d_all_len)))
+
+    def fence(self, ctx, lag=0):
+        self._check(self.lib.xb_comm_fence(self.h, ctx.h, int(lag)))
+
+    def synchronize(self):
+        self._check(self.lib.xb_comm_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.xb_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

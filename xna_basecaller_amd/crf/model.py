@@ -10,6 +10,7 @@ reference so that util.load_model/match_names work unchanged).  No torch op runs
 decode: both call the hand-written HIP kernels through the C ABI (include/xna_basecaller.h).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -61,6 +62,80 @@ class CTC_CRF:
         ip = np.exp(b0)
         ip /= ip.sum(axis=-1, keepdims=True)
         return tp, ip
+
+    # ---- CTC-CRF loss scans (crf/model.py:102-135): the lattice arithmetic runs on the device (xb_ctc_logz /
+    #      xb_ctc_alignments through the owning Model's context); gathers and scatters of a few MB stay on the host ----
+    def _ctc_indices(self, targets):
+        """Gather columns of prepare_ctc_scores: (stay_idx (N, n), move_idx (N, n - 1)), n = Lt - state_len + 1."""
+        t = np.clip(np.asarray(targets, dtype=np.int64) - 1, 0, None)          # CTC labels (blank = 0) -> zero-based bases
+        nb, sl = self.n_base, self.state_len
+        n = t.shape[1] - (sl - 1)
+        stay = sum(t[:, i:n + i] * nb ** (sl - i - 1) for i in range(sl)) * len(self.alphabet)
+        move = stay[:, 1:] + t[:, :n - 1] + 1
+        return stay, move
+
+    def prepare_ctc_scores(self, scores, targets):
+        """(T,N,C) scores, (N,Lt) targets -> (stay_scores (T,N,n), move_scores (T,N,n-1)) (crf/model.py:102-116)."""
+        scores = np.asarray(scores, dtype=np.float32)
+        stay, move = self._ctc_indices(targets)
+        T = scores.shape[0]
+        return (np.take_along_axis(scores, np.broadcast_to(stay[None], (T,) + stay.shape), axis=2),
+                np.take_along_axis(scores, np.broadcast_to(move[None], (T,) + move.shape), axis=2))
+
+    def _owner(self):
+        m = getattr(self, "_model", None)
+        m = m() if m is not None else None
+        if m is None:
+            raise RuntimeError("the CTC scans run on the device: use the CTC_CRF of a Model (model.seqdist)")
+        return m
+
+    def ctc_loss(self, scores, targets, target_lengths, loss_clip=None, reduction="mean", normalise_scores=True,
+                 want_grad=False):
+        """
+        crf/model.py:118-131: loss = -logZ_ctc(normalised scores) / target_length, clipped, mean / none.
+        want_grad=True also returns d loss / d scores (T,N,C) -- what the reference obtains by autograd through seqdist:
+        -(R - P) / length per chunk, with R the restricted posteriors scattered over (stay_idx, move_idx) and, when the
+        scores were normalised here, P = the CRF's edge posteriors (every time step carries exactly one edge of a path,
+        so the normalisation's own derivative is -P); zero where the loss was clipped, / N for the mean.
+        """
+        m = self._owner()
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, N, _ = scores.shape
+        tl = np.asarray(target_lengths, dtype=np.int32)
+        x = m.normalise(scores) if normalise_scores else scores
+        ctx = m.context(T * m.stride, N)
+        out = ctx.ctc_logz(x, targets, tl, want_grads=want_grad)
+        loss = -(out["logz"] / tl.astype(np.float32))
+        live = np.ones(N, dtype=bool)
+        if loss_clip:
+            live = (loss >= 0.0) & (loss <= loss_clip)
+            loss = np.clip(loss, 0.0, np.float32(loss_clip))
+        if reduction == "mean":
+            value = loss.mean(dtype=np.float32)
+        elif reduction in ("none", None):
+            value = loss
+        else:
+            raise ValueError("Unknown reduction type {}".format(reduction))
+        if not want_grad:
+            return value
+        stay, move = self._ctc_indices(targets)
+        grad = np.zeros_like(scores)
+        bi = np.arange(N)[:, None]
+        for t in range(T):                                   # repeated k-mers hit the same column: unbuffered adds
+            np.add.at(grad[t], (bi, stay), out["stay"][t])
+            np.add.at(grad[t], (bi, move), out["move"][t])
+        if normalise_scores:
+            grad -= m.posteriors(scores)
+        w = -(live / tl.astype(np.float32)) / (np.float32(N) if reduction == "mean" else np.float32(1))
+        return value, grad * w[None, :, None].astype(np.float32)
+
+    def ctc_viterbi_alignments(self, scores, targets, target_lengths):
+        """crf/model.py:133-135: (T,N,n) one-hot alignment of the best path through the targets' stay / move lattice."""
+        m = self._owner()
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, N, _ = scores.shape
+        al, _ = m.context(T * m.stride, N).ctc_alignments(scores, targets, np.asarray(target_lengths, dtype=np.int32))
+        return al
 
     def reverse_complement(self, scores):
         """crf/model.py:78-90 on a host (T,N,C) array: flip time, complement every k-mer index."""
@@ -192,6 +267,7 @@ class Model(torch.nn.Module):
     def __init__(self, config):
         super().__init__()
         self.seqdist = CTC_CRF(state_len=config["global_norm"]["state_len"], alphabet=config["labels"]["labels"])
+        self.seqdist._model = weakref.ref(self)        # the CTC scans of model.seqdist run on this model's device context
         if "type" in config["encoder"]:          # new-style (typed) config, crf/model.py:231-232
             self.encoder, enc = encoder_from_dict(config["encoder"], self.seqdist.n_base, self.seqdist.state_len)
         else:                                      # old-style: keyword arguments of rnn_encoder

@@ -170,8 +170,8 @@ int collect_events(xb_ctx *ctx)
         float ms = 0.f;
         if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
             ctx->stage_ms[ev.stage] += ms;
-        hipEventDestroy(ev.a);
-        hipEventDestroy(ev.b);
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
     }
     ctx->events.clear();
     return XB_OK;
@@ -310,7 +310,8 @@ int check_device_error(xb_ctx *ctx)
     XB_HIP(ctx, hipMemcpyAsync(&e, ctx->error, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
     XB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (e != 0) {
-        hipMemsetAsync(ctx->error, 0, sizeof(unsigned), ctx->stream);
+        (void)hipMemsetAsync(ctx->error, 0, sizeof(unsigned), ctx->stream);
+        if (e == 2u) return fail(ctx, XB_ERR_DEVICE, "CTC scan: a target length was outside the lattice");
         return fail(ctx, XB_ERR_DEVICE, "LSTM inter-workgroup sync timed out (persistent kernel was not fully resident?)");
     }
     return XB_OK;
@@ -701,7 +702,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
 XB_API void xb_ctx_destroy(xb_ctx *ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
@@ -716,9 +717,9 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
     }
     if (ctx->stream_copy) { (void)hipStreamSynchronize(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_copy); }
     for (auto &e : ctx->deps) (void)hipEventDestroy(e);
-    for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-    for (auto &b : ctx->bufs) hipFree(b.p);
-    for (void *w : ctx->wbufs) hipFree(w);
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto &b : ctx->bufs) (void)hipFree(b.p);
+    for (void *w : ctx->wbufs) (void)hipFree(w);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
@@ -848,6 +849,16 @@ XB_API void *xb_result_stream(xb_ctx *ctx)
     return ctx->result_stream ? ctx->result_stream : ctx->stream;
 }
 
+XB_API int xb_stream_wait_event(xb_ctx *ctx, void *hip_event)
+{
+    if (!ctx || !hip_event) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev = static_cast<hipEvent_t>(hip_event);
+    XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+    if (ctx->stream3) XB_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ev, 0));
+    return XB_OK;
+}
+
 XB_API int xb_encode_dev(xb_ctx *ctx, const float *d_signal, int n, int expand_blanks, float *d_scores)
 {
     int rc = check_ready(ctx, n);
@@ -965,6 +976,109 @@ XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int
 XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, float *logz)
 {
     return xb_crf_scans(ctx, scores, T, n, has_blank, nullptr, nullptr, logz, nullptr);
+}
+
+// prepare_ctc_scores' gather columns (crf/model.py:102-116) for n targets of Lt labels: np = Lt - (sl - 1) positions
+static void ctc_indices(const int32_t *targets, int n, int Lt, int nb, int sl, std::vector<int32_t> &stay, std::vector<int32_t> &move)
+{
+    const int np = Lt - (sl - 1), E = nb + 1;
+    stay.assign((size_t)n * np, 0);
+    move.assign((size_t)n * (np > 1 ? np - 1 : 1), 0);
+    for (int b = 0; b < n; ++b) {
+        for (int l = 0; l < np; ++l) {
+            int64_t st = 0;
+            for (int i = 0; i < sl; ++i) {
+                const int v = std::max(targets[(size_t)b * Lt + l + i] - 1, 0);        // torch.clamp(targets - 1, 0)
+                st += (int64_t)v * ipow(nb, sl - i - 1);
+            }
+            stay[(size_t)b * np + l] = (int32_t)(st * E);
+        }
+        for (int l = 0; l + 1 < np; ++l)
+            move[(size_t)b * (np - 1) + l] = stay[(size_t)b * np + l + 1] + std::max(targets[(size_t)b * Lt + l] - 1, 0) + 1;
+    }
+}
+
+static int run_ctc(xb_ctx *ctx, const float *scores, int T, int n, const int32_t *targets, int Lt, const int32_t *tlen,
+                   int semiring, float *logz, float *gstay, float *gmove)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    const int sl = ctx->cfg.state_len, nb = ctx->cfg.n_base, S = ctx->S, C = S * (nb + 1);
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    if (!scores || !targets || !tlen) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    if (!logz && !gstay && !gmove) return fail(ctx, XB_ERR_INVALID, "no output requested");
+    const int np = Lt - (sl - 1);
+    if (np < 1 || np > xb::ctc_max_positions())
+        return fail(ctx, XB_ERR_INVALID, "target width %d gives %d positions, supported: 1..%d", Lt, np, xb::ctc_max_positions());
+    for (int b = 0; b < n; ++b) {
+        if (tlen[b] < sl || tlen[b] > Lt)
+            return fail(ctx, XB_ERR_INVALID, "target_lengths[%d] = %d outside [state_len = %d, %d]", b, tlen[b], sl, Lt);
+        for (int l = 0; l < Lt; ++l)
+            if (targets[(size_t)b * Lt + l] < 0 || targets[(size_t)b * Lt + l] > nb)
+                return fail(ctx, XB_ERR_INVALID, "targets[%d][%d] = %d outside [0, n_base = %d]", b, l, targets[(size_t)b * Lt + l], nb);
+    }
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcj = join_async_decode(ctx)) return rcj;
+    std::vector<int32_t> stay, move;
+    ctc_indices(targets, n, Lt, nb, sl, stay, move);
+    const size_t nm = np > 1 ? np - 1 : 1;
+    // per-call device scratch (a training-side operator: sizes follow the targets, not the context)
+    int32_t *d_stay = nullptr, *d_move = nullptr, *d_len = nullptr;
+    float *d_alpha = nullptr, *d_gs = nullptr, *d_gm = nullptr;
+    int rc = XB_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_stay); (void)hipFree(d_move); (void)hipFree(d_len); (void)hipFree(d_alpha); (void)hipFree(d_gs); (void)hipFree(d_gm);
+    };
+#define XB_CTC_HIP(call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            rc = fail(ctx, e_ == hipErrorOutOfMemory ? XB_ERR_NOMEM : XB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            cleanup();                                                                        \
+            return rc;                                                                        \
+        }                                                                                     \
+    } while (0)
+    const bool grads = gstay || gmove;
+    XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_stay), sizeof(int32_t) * stay.size()));
+    XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_move), sizeof(int32_t) * move.size()));
+    XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_len), sizeof(int32_t) * (size_t)n));
+    if (grads) {
+        XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_alpha), sizeof(float) * (size_t)n * (T + 1) * np));
+        XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_gs), sizeof(float) * (size_t)T * n * np));
+        if (gmove) XB_CTC_HIP(hipMalloc(reinterpret_cast<void **>(&d_gm), sizeof(float) * (size_t)T * n * nm));
+    }
+    hipStream_t st = ctx->stream;
+    ctx->result_stream = st;
+    XB_CTC_HIP(hipMemcpyAsync(d_stay, stay.data(), sizeof(int32_t) * stay.size(), hipMemcpyHostToDevice, st));
+    XB_CTC_HIP(hipMemcpyAsync(d_move, move.data(), sizeof(int32_t) * move.size(), hipMemcpyHostToDevice, st));
+    XB_CTC_HIP(hipMemcpyAsync(d_len, tlen, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    XB_CTC_HIP(hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * C, hipMemcpyHostToDevice, st));
+    if (d_gs) XB_CTC_HIP(hipMemsetAsync(d_gs, 0, sizeof(float) * (size_t)T * n * np, st));
+    if (d_gm) XB_CTC_HIP(hipMemsetAsync(d_gm, 0, sizeof(float) * (size_t)T * n * nm, st));
+    xb::CtcParams p{};
+    p.scores = ctx->scores; p.T = T; p.N = n; p.C = C; p.stay_idx = d_stay; p.move_idx = d_move; p.n = np; p.tlen = d_len;
+    p.sl = sl; p.semiring = semiring; p.alpha = d_alpha; p.logz = ctx->logz; p.gstay = d_gs; p.gmove = d_gm; p.error = ctx->error;
+    XB_CTC_HIP(xb::launch_ctc_scan(p, st));
+    if (logz) XB_CTC_HIP(hipMemcpyAsync(logz, ctx->logz, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (gstay) XB_CTC_HIP(hipMemcpyAsync(gstay, d_gs, sizeof(float) * (size_t)T * n * np, hipMemcpyDeviceToHost, st));
+    if (gmove && np > 1) XB_CTC_HIP(hipMemcpyAsync(gmove, d_gm, sizeof(float) * (size_t)T * n * nm, hipMemcpyDeviceToHost, st));
+    XB_CTC_HIP(hipStreamSynchronize(st));
+#undef XB_CTC_HIP
+    cleanup();
+    return check_device_error(ctx);
+}
+
+XB_API int xb_ctc_logz(xb_ctx *ctx, const float *scores, int T, int n, const int32_t *targets, int Lt,
+                       const int32_t *target_lengths, float *logz, float *gstay, float *gmove)
+{
+    return run_ctc(ctx, scores, T, n, targets, Lt, target_lengths, 0, logz, gstay, gmove);
+}
+
+XB_API int xb_ctc_alignments(xb_ctx *ctx, const float *scores, int T, int n, const int32_t *targets, int Lt,
+                             const int32_t *target_lengths, float *alignments, float *max_score)
+{
+    if (!alignments) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    return run_ctc(ctx, scores, T, n, targets, Lt, target_lengths, 1, max_score, alignments, nullptr);
 }
 
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet, int8_t *d_seq,

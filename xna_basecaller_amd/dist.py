@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "env_rank_world", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier",
+__all__ = ["init_from_env", "env_rank_world", "exchange_comm_id", "RcclGather", "rank", "world_size", "shard", "gather_called", "gather_packed", "barrier",
            "DeferredGather"]
 
 
@@ -170,3 +170,92 @@ class DeferredGather:
         if done is not None:
             done.synchronize()
         return out
+
+
+def exchange_comm_id(rank_, world, make_id, port_offset=1, timeout=120.0):
+    """
+    Out-of-band hand-off of the 128-byte communicator id (xb_comm_unique_id) from rank 0 to the other ranks.  With
+    torch.distributed up (torchrun) its store carries it; otherwise a one-shot TCP rendezvous on MASTER_ADDR :
+    MASTER_PORT + port_offset (rank 0 listens and serves world - 1 connections; the others retry until it is up).
+    """
+    if world <= 1:
+        return make_id()
+    if dist.is_available() and dist.is_initialized():
+        box = [make_id() if rank_ == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    import socket
+    import time
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + int(port_offset)
+    deadline = time.monotonic() + timeout
+    if rank_ == 0:
+        cid = make_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(cid)
+        return cid
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as c:
+                buf = b""
+                while len(buf) < 128:
+                    part = c.recv(128 - len(buf))
+                    if not part:
+                        raise ConnectionError("short communicator id")
+                    buf += part
+                return buf
+        except (ConnectionError, OSError):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.2)
+
+
+class RcclGather:
+    """
+    The gather of called sequences through the C ABI (xb_comm / xb_gather_called: RCCL all-gathers on the communicator's own
+    stream behind the context's result stream) -- DeferredGather's job without torch.distributed on the data path.
+    `submit` enqueues the gather of the batch just handed in (it starts on the device when that batch is complete, while the
+    next batch computes) and returns the PREVIOUS batch's gathered (seq (world, n, T), lens (world, n)) device tensors;
+    `before_batch` orders the producer behind the gather that last read the buffer set it is about to overwrite (two sets
+    in rotation); `flush` completes the last one.
+    """
+
+    def __init__(self, ctx, device_index, rank_, world):
+        from . import _lib
+        self.ctx, self.world = ctx, int(world)
+        cid = exchange_comm_id(rank_, world, _lib.Comm.unique_id)
+        self.comm = _lib.Comm(device_index, rank_, world, cid)
+        self._out = {}
+        self._prev = None
+        self._k = 0
+
+    def before_batch(self):
+        self.comm.fence(self.ctx, lag=1)
+
+    def submit(self, seq, lens):
+        n, T = int(seq.shape[0]), int(seq.shape[1])
+        slot = self._k & 1
+        key = (slot, n, T)
+        if key not in self._out:
+            self._out[key] = (torch.empty((self.world, n, T), dtype=torch.int8, device=seq.device),
+                              torch.empty((self.world, n), dtype=torch.int32, device=seq.device))
+        all_seq, all_len = self._out[key]
+        self.comm.gather_called(self.ctx, seq.data_ptr(), lens.data_ptr(), n, T, all_seq.data_ptr(), all_len.data_ptr())
+        prev, self._prev = self._prev, (all_seq, all_len)
+        self._k += 1
+        return prev
+
+    def flush(self):
+        self.comm.synchronize()
+        prev, self._prev = self._prev, None
+        return prev
+
+    def close(self):
+        self.comm.close()
