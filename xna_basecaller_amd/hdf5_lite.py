@@ -644,9 +644,11 @@ class Dataset(_Object):
         pos, _ = self.find(0x0008)[0]
         ver = buf.u(pos, 1)
         count = int(np.prod(shape)) if shape else 1
-        if ver != 3:
-            raise Hdf5Error("data layout version %d not supported" % ver)
         cls = buf.u(pos + 1, 1)
+        # version 4 (files written with the 1.10 format) keeps version 3's compact and contiguous forms and replaces the
+        # chunk B-tree by new chunk indexes, which are not implemented (no fast5 writer produces them)
+        if ver != 3 and not (ver == 4 and cls in (0, 1)):
+            raise Hdf5Error("data layout version %d%s not supported" % (ver, " (chunked)" if ver == 4 else ""))
         if cls == 0:
             size = buf.u(pos + 2, 2)
             out = np.frombuffer(bytes(buf.d[pos + 4:pos + 4 + size]), dtype=dt.np, count=count)
