@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--lstm-mode", type=int, default=0)
+    ap.add_argument("--weights", default="seeded", choices=["seeded", "peaky"],
+                    help="seeded: N(0, 1/sqrt(fan_in)) weights (flat posteriors: every step calls a base); peaky: "
+                         "synthetic.peaky_weights (scores follow the signal, ~0.5 bases per step: a trained model's regime)")
     ap.add_argument("--gather", default="xb", choices=["xb", "torch"],
                     help="N > 1: xb = xb_gather_called over librccl (C ABI); torch = torch.distributed all_gather")
     ap.add_argument("--force-gather", action="store_true",
@@ -96,7 +99,7 @@ def main():
     import torch
     from xna_basecaller_amd import _lib
     from xna_basecaller_amd import dist as xdist
-    from xna_basecaller_amd.synthetic import seeded_weights
+    from xna_basecaller_amd.synthetic import peaky_weights, seeded_weights
 
     rank, world = xdist.init_from_env()
     if world != max(args.gpus, 1):
@@ -112,7 +115,7 @@ def main():
     prec = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8,
             "f16f8i": _lib.XB_PREC_F16F8_IN1}[args.precision]
     ctx = _lib.Context(local, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=prec, lstm_mode=args.lstm_mode)
-    sd = seeded_weights(F, nb)
+    sd = peaky_weights(F, nb) if args.weights == "peaky" else seeded_weights(F, nb)
     ctx.load_state_dict(sd)
     T = ctx.T
 
@@ -234,7 +237,9 @@ def main():
                   1: "f16 MFMA, f32 accumulate; CRF decode f32",
                   2: "f32 (f16 MFMA + FP8 block-scaled correction MFMA, f32 accumulate; CRF decode f32)",
                   3: "f32 (as f16f8, LSTM input projections f16 MFMA only, f32 accumulate; |score err| <= 1e-3; CRF decode f32)"}[prec],
-        "data": "synthetic N(0,1) signal chunks generated in HBM; seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout",
+        "data": "synthetic N(0,1) signal chunks generated in HBM; " +
+                ("seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout" if args.weights == "seeded" else
+                 "synthetic.peaky_weights (zero LSTM biases, input gain 2, CRF linear gain 10 / bias -2) in the reference state-dict layout"),
         "config": {"workload": "BASELINE configs[%s]: %d-base CRF (S=%d, C=%d), chunksize %d, batch %d per GPU, features %d"
                                % ({(5, 512): "1", (6, 512): "2", (6, 1024): "3] per-GPU workload [1 of 8 ranks",
                                    (6, 2048): "4] per-GPU workload [1 of 8 ranks"}.get((nb, N), "-"), nb, S, S * E, L, N, F),
@@ -244,7 +249,7 @@ def main():
         "stage_ms_per_step": {k: v[0] / K for k, v in stages.items()},
         "stage_note": "HIP-event time per stage on its own stream; lstm_in / linear run slab by slab on a second stream "
                       "beside the previous layer's recurrence, so the stages overlap and do not add up to ms_per_step",
-        "called_bases_last_step": called,
+        "called_bases_last_step": called, "called_bases_per_time_step": called / float(N * T),
     }
     if world == 1 and args.cpu_chunks > 0:
         out["cpu_baseline"] = cpu_baseline(sd, F, nb, L, args.cpu_chunks, alphabet, args.cpu_repeats)

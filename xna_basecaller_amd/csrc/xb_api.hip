@@ -77,6 +77,7 @@ struct xb_ctx {
     // projections also as hi-only images for XB_PREC_F16F8_IN1
     unsigned char *w3_f4 = nullptr, *wih_f4[5] = {}, *wih_f4h[5] = {}, *wl_f4 = nullptr;
     size_t w3_ks = 0, wih_ks = 0, wih_ksh = 0, wl_ks = 0;
+    int gemm_shadow_wgs = 2;                   // XB_GEMM_SHADOW_WGS=1: GEMM slabs beside the recurrence run one workgroup per CU
     int gemm4 = 1;                             // XB_GEMM4=0: gemm8r_kernel (one workgroup per CU) instead of gemm4p_kernel (A/B comparisons)
     std::vector<void *> wbufs;                 // weight allocations of the current xb_weights_ready (freed by the next one)
     int8_t *whh_q1[5] = {}, *whh_q0[5] = {};   // int8-limb recurrence (lstm_i8): balanced digits of W_hh, gate-interleaved rows
@@ -99,6 +100,7 @@ struct xb_ctx {
     int lstm_resident = -1;      // workgroups of the persistent kernel admitted per CU (occupancy query, lazily)
     int lstm_dual_resident = -1; // the same for the two-groups-per-workgroup variant (larger LDS footprint)
     int in1_layers = 31;         // XB_IN1_LAYERS (diagnostic): layers whose input projection XB_PREC_F16F8_IN1 reduces
+    int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
     bool profiling = false;
@@ -333,7 +335,7 @@ struct NextGemm {
     int ldc, expand;
 };
 
-int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipStream_t st)
+int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipStream_t st, bool shadow = false)
 {
     const xb_config &c = ctx->cfg;
     const int F = c.features;
@@ -342,6 +344,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     g.a_hi = ng.x_hi + r0 * F; g.a_lo = ng.x_lo + r0 * F;
     g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = precision_nsplit(ctx);
     g.ldc = ng.ldc; g.out_f32 = ng.out + r0 * ng.ldc;
+    g.one_per_cu = shadow && ctx->gemm_shadow_wgs == 1;
     if (ng.layer < 5) {
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
@@ -437,6 +440,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                     // counters are zeroed once per layer (above): consecutive launches follow each other without a memset in
                     // between, so the next launch's workgroups are dispatched the moment the previous one retires
                     p.grp0 = global_groups ? n0 / bn : 0;
+                    p.slab = i; p.xcd_local = ctx->lstm_local && i < 16;   // 16 mask bytes per group slot
                     p.sync_base = global_groups ? arrivals : 0;
                     if (!global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
                     XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
@@ -450,7 +454,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 XB_HIP(ctx, hipEventRecord(ev, ctx->stream));
                 XB_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev, 0));
                 const int ta = p.reverse ? T - s1 : s0, tb = p.reverse ? T - s0 : s1;
-                if ((rc = launch_row_gemm(ctx, *next, n, ta, tb, ctx->stream2))) return rc;
+                if ((rc = launch_row_gemm(ctx, *next, n, ta, tb, ctx->stream2, true))) return rc;
             }
         }
         if (overlapped && ctx->overlap == 1) {
@@ -626,9 +630,11 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     ctx->lstm_mode = cfg->lstm_mode;
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
+    if (const char *e = getenv("XB_LSTM_LOCAL")) ctx->lstm_local = atoi(e) != 0;
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
     if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
     if (const char *e = getenv("XB_GEMM4")) ctx->gemm4 = atoi(e) != 0;
+    if (const char *e = getenv("XB_GEMM_SHADOW_WGS")) ctx->gemm_shadow_wgs = atoi(e) == 1 ? 1 : 2;
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \

@@ -895,6 +895,13 @@ __device__ __forceinline__ void dma16_sc1(const void *g, void *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, CPOL_SC1);
 }
 
+// 16-byte plain store: the line stays in the XCD's L2 (same asm form as the write-through one below)
+__device__ __forceinline__ void store16_l2(void *g, uint4 v)
+{
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(d) : "memory");
+}
+
 // 16-byte write-through store (the `s_nop 1` keeps the data registers intact until the store has read them)
 __device__ __forceinline__ void store16_sc1(void *g, uint4 v)
 {
@@ -1047,6 +1054,20 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
     }
 
+    // ---- same-XCD exchange (round 3).  A write-through (sc1) store DROPS the line from the XCD's L2, so every member's h
+    //      fetch of the next step starts with a fabric round trip; a plain store keeps it there, and a group's members
+    //      normally share an XCD (blocks b, b + 8, .. under round-robin dispatch).  "Normally" is not a contract, so the
+    //      members PROVE it per launch: each ORs the bit of the XCD it actually runs on (HW_REG_XCC_ID) into a word of its
+    //      group's sync slot; when a member's first wait for the group has completed, every member has posted its bit (the OR
+    //      is older than the member's first arrival), and a mask with exactly one bit set switches this workgroup's later
+    //      exchange stores to plain ones (the loads stay sc1 = L2-served).  Any other mask -- members on several XCDs, the
+    //      placement test -- keeps the write-through form, which is correct anywhere.  One-group-per-workgroup kernel only.
+    // (mask word and shift are recomputed from the kernel arguments where they are used: nothing extra stays live in the loop)
+    if (!DUAL && p.persistent && p.xcd_local && tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;        // HW_REG_XCC_ID[3:0]
+        __hip_atomic_fetch_or(cnt + 1 + ((p.slab >> 2) & 3), 1u << (8 * (p.slab & 3) + xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) sFlag[2] = 0;
 #ifdef XB_LSTM_STAMPS
     unsigned long long *sStamp = reinterpret_cast<unsigned long long *>(sFlag + 4);
     if (tid == 0) for (int i = 0; i < 10; ++i) sStamp[i] = 0;
@@ -1185,6 +1206,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                                 }
                             }
                             *sFlag = ok;
+                            if (!DUAL && p.xcd_local && s == p.s_begin + 1) {
+                                const unsigned m = (__hip_atomic_load(cnt + 1 + ((p.slab >> 2) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
+                                                    (8 * (p.slab & 3))) & 0xffu;
+                                sFlag[2] = (m != 0 && (m & (m - 1)) == 0) ? 1 : 0;      // all members on ONE XCD
+                            }
                         }
                         __syncthreads();
                         if (*sFlag == 0) return;
@@ -1480,8 +1506,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     store16_sc1(xb, vd);
                 } else {
                 half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
-                store16_sc1(xcur, vhi);
-                if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
+                if (!DUAL && __builtin_amdgcn_readfirstlane(sFlag[2]) != 0) {      // the group sits on one XCD (proven above)
+                    store16_l2(xcur, vhi);
+                    if (NSPLIT != 1) store16_l2(xcur + XPART, vlo);
+                } else {
+                    store16_sc1(xcur, vhi);
+                    if (NSPLIT != 1) store16_sc1(xcur + XPART, vlo);
+                }
                 }
             }
             XB_STAMP(4);   // pointwise + exchange stores issued
@@ -1605,7 +1636,14 @@ hipError_t launch_gemm4p_ns(const xb::GemmParams &p, hipStream_t stream)
     const int SN = NT < 4 ? NT : 4, SM = 64 / SN;
     const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see gemm4_tile_origin
     dim3 grid(8 * 64 * ((supers + 7) / 8)), block(G4_THREADS);
-    const size_t lds = (size_t)3 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;       // [3 stages][parts][128 rows x 64 B]
+    size_t lds = (size_t)3 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;             // [3 stages][parts][128 rows x 64 B]
+    if (p.one_per_cu) {
+        // a launch that shares the chip with the recurrence: more than half of a CU's LDS keeps it to ONE workgroup per CU
+        // (half the memory traffic per CU on the recurrence's L2 / fabric), see xb_api.hip run_lstm_layer
+        lds = 96 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm4p_kernel<EPI, NSPLIT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     hipLaunchKernelGGL((gemm4p_kernel<EPI, NSPLIT>), grid, block, lds, stream, p);
     return hipGetLastError();
 }

@@ -93,6 +93,7 @@ struct GemmParams {
     // is set; otherwise gemm8r_kernel (one 256 x 256 workgroup per CU, both operands through LDS; kept as the A/B reference)
     const unsigned char *b4;     // [K / 32][rows4 / 32][pieces][64 lanes][16 B], rows4 = Nn rounded up to 256 (zero rows)
     size_t b4_kstride;           // bytes between consecutive k-tiles of b4 = rows4 / 32 * pieces * 1024
+    int one_per_cu;              // gemm4p: 1 = at most one workgroup per CU (launches beside the recurrence)
 };
 // pieces per 32-row block and k-tile of the fragment-major image for a given nsplit (lane l = 32 h + r holds row r):
 //   piece 0, 1: the 8 fp16 `hi` values of columns 32 kt + 16 ks + 8 h .. + 8, ks = 0, 1
@@ -137,6 +138,9 @@ struct LstmParams {
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
     int dual;                    // 1: a workgroup serves two groups alternately (a launch then holds twice the groups)
+    int slab;                    // index of this launch among the layer's time slabs (selects the byte of the XCD mask below)
+    int xcd_local;               // 1: members prove per launch that their group sits on one XCD (words 1..4 of the group's sync
+                                 // slot, one byte per time slab, zeroed with the counters) and then exchange h with plain stores
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
