@@ -1,16 +1,22 @@
+# The command list behind profiles/r03_* (one GPU call; run from the repo root on the GPU box):
+#   bench lines of the default build (configs[2], configs[1], the per-GPU workloads of configs[3] / [4], the peaky model),
+#   the recurrence's cycle stamps (diagnostic library), rocprofv3 kernel-trace stats of the bench command, and the PMC passes
+#   (FETCH_SIZE / WRITE_SIZE for roofline.traffic; MFMA-busy / clock / L2 for the GEMM and the recurrence).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/v3; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 > $O/bench_nb6.json 2> $O/bench_nb6.err
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 --nbase 5 --cpu-chunks 0 > $O/bench_nb5.json 2>> $O/bench_nb6.err
-timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 > $O/bench_n1024.json 2>> $O/bench_nb6.err
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --batch 2048 --cpu-chunks 0 > $O/bench_n2048.json 2>> $O/bench_nb6.err
-timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 --precision f16f8i > $O/bench_n1024_f16f8i.json 2>> $O/bench_nb6.err
-XB_LSTM_DUAL=0 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 > $O/bench_n1024_single.json 2>> $O/bench_nb6.err
-(export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1)
+timeout -k 10 300 python bench.py --steps 6 --warmup 2 > $O/bench_nb6.json 2> $O/bench.err
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --nbase 5 --cpu-chunks 0 > $O/bench_nb5.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 > $O/bench_n1024.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --batch 2048 --cpu-chunks 0 > $O/bench_n2048.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 4 --warmup 2 --weights peaky --cpu-chunks 0 > $O/bench_nb6_peaky.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 448 --cpu-chunks 0 > $O/bench_n448.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 98 --cpu-chunks 0 > $O/bench_n98.json 2>> $O/bench.err
+XB_OVERLAP=0 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --cpu-chunks 0 > $O/bench_nb6_serial.json 2>> $O/bench.err
+(export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1024 -- python3 $R/bench.py --steps 4 --warmup 2 --cpu-chunks 0 --batch 1024 > $O/stats1024.log 2>&1
 cd $R
-PASSES=2 bash tools/pmc_gemm.sh v3/pmc512 > $O/pmc512.log 2>&1
+bash tools/pmc_gemm.sh r03/pmc512 > $O/pmc512.log 2>&1
+XB_OVERLAP=0 bash tools/pmc_gemm.sh r03/pmc512_serial > $O/pmc512_serial.log 2>&1
 echo done > $O/done.txt

@@ -29,7 +29,7 @@ def main():
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kernels = {}
     for name, d in agg.items():
-        if not any(k in name for k in ("conv_front", "gemm8r", "lstm_kernel", "crf_decode")):
+        if not any(k in name for k in ("conv_front", "gemm8r", "gemm4p", "lstm_kernel", "crf_decode")):
             continue
         n = max(len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"]), 1)
         fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)

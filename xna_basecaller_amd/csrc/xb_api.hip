@@ -77,6 +77,7 @@ struct xb_ctx {
     // projections also as hi-only images for XB_PREC_F16F8_IN1
     unsigned char *w3_f4 = nullptr, *wih_f4[5] = {}, *wih_f4h[5] = {}, *wl_f4 = nullptr;
     size_t w3_ks = 0, wih_ks = 0, wih_ksh = 0, wl_ks = 0;
+    int gemm_shadow_kernel = 0;                // XB_GEMM_SHADOW: 0 auto (by batch size), 4 gemm4p_kernel, 8 gemm8r_kernel for the slabs beside the recurrence
     int gemm_shadow_wgs = 2;                   // XB_GEMM_SHADOW_WGS=1: GEMM slabs beside the recurrence run one workgroup per CU
     int gemm4 = 1;                             // XB_GEMM4=0: gemm8r_kernel (one workgroup per CU) instead of gemm4p_kernel (A/B comparisons)
     std::vector<void *> wbufs;                 // weight allocations of the current xb_weights_ready (freed by the next one)
@@ -345,15 +346,20 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = precision_nsplit(ctx);
     g.ldc = ng.ldc; g.out_f32 = ng.out + r0 * ng.ldc;
     g.one_per_cu = shadow && ctx->gemm_shadow_wgs == 1;
+    // which kernel: gemm4p_kernel, except for the slabs that run beside the two-groups-per-workgroup recurrence of a batch
+    // above 1024 chunks, where the one-workgroup-per-CU gemm8r_kernel disturbs the recurrence less (same box, ms per step at
+    // batch 2048: 477 vs 488 (gemm4p, one workgroup per CU) vs 499; batch 1024: 240 vs 246 vs 235; batch 512: 126.7 vs 129.7 vs
+    // 123.0 -- profiles/r03_gemm_kernel_by_batch.txt).  XB_GEMM_SHADOW=4 / 8 forces one of them.
+    const bool use4 = ctx->gemm4 && !(shadow && (ctx->gemm_shadow_kernel == 8 || (ctx->gemm_shadow_kernel == 0 && n > 1024)));
     if (ng.layer < 5) {
         StageScope sc(ctx, XB_STAGE_LSTM_IN, 1, st);
         g.b_hi = ctx->wih_hi[ng.layer]; g.b_lo = ctx->wih_lo[ng.layer]; g.Nn = 4 * F; g.bias = ctx->lbias[ng.layer];
         // main product only (the q8 images stay unused) -- in1_layers: bit l = input projection of layer l (diagnostic
         // XB_IN1_LAYERS, default all five)
-        if (ctx->gemm4) { g.b4 = ctx->wih_f4[ng.layer]; g.b4_kstride = ctx->wih_ks; }
+        if (use4) { g.b4 = ctx->wih_f4[ng.layer]; g.b4_kstride = ctx->wih_ks; }
         if (ctx->cfg.precision == XB_PREC_F16F8_IN1 && ((ctx->in1_layers >> ng.layer) & 1)) {
             g.nsplit = 1;
-            if (ctx->gemm4) { g.b4 = ctx->wih_f4h[ng.layer]; g.b4_kstride = ctx->wih_ksh; }
+            if (use4) { g.b4 = ctx->wih_f4h[ng.layer]; g.b4_kstride = ctx->wih_ksh; }
         }
         g.a_exp = ng.layer == 0 ? 0 : 8; g.b_exp = ctx->wih_exp[ng.layer];     // conv3 output / LSTM output
         g.gin_n = n;                                                           // member-major gin (xb_internal.h)
@@ -363,7 +369,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
         g.b_hi = ctx->wl_hi; g.b_lo = ctx->wl_lo; g.Nn = ctx->O; g.bias = ctx->bl;
         g.scale = c.scale; g.nb = c.n_base; g.expand = ng.expand; g.blank = c.blank_score;
         g.a_exp = 8; g.b_exp = ctx->wl_exp;
-        if (ctx->gemm4) { g.b4 = ctx->wl_f4; g.b4_kstride = ctx->wl_ks; }
+        if (use4) { g.b4 = ctx->wl_f4; g.b4_kstride = ctx->wl_ks; }
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_TANH_SCALE, st));
     }
     return XB_OK;
@@ -635,6 +641,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
     if (const char *e = getenv("XB_GEMM4")) ctx->gemm4 = atoi(e) != 0;
     if (const char *e = getenv("XB_GEMM_SHADOW_WGS")) ctx->gemm_shadow_wgs = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("XB_GEMM_SHADOW")) ctx->gemm_shadow_kernel = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
 
 #define XB_CREATE_HIP(call)                                                                   \
     do {                                                                                      \

@@ -568,9 +568,9 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #undef G8_READ_B
 
     // the epilogue's per-lane indices must not be computed (and kept in registers) ahead of the main loop
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    gemm_epilogue<EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, lane_e);
+    int lane_e = lane, mw_e = m0 + wr * 128, nw_e = n0 + wc * 64;
+    asm volatile("" : "+v"(lane_e), "+s"(mw_e), "+s"(nw_e));       // (the tile origin too: its divisions belong behind the loop)
+    gemm_epilogue<EPI>(p, acc, mw_e, nw_e, lane_e);
 }
 
 // ======================================================================================
@@ -859,9 +859,9 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 #undef G4P_MFMA_END
 #undef G4P_SB
 
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    gemm_epilogue<EPI>(p, acc, m0, n0 + wid * 64, lane_e);
+    int lane_e = lane, mw_e = m0, nw_e = n0 + wid * 64;
+    asm volatile("" : "+v"(lane_e), "+s"(mw_e), "+s"(nw_e));
+    gemm_epilogue<EPI>(p, acc, mw_e, nw_e, lane_e);
 }
 
 // ======================================================================================
