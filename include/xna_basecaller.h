@@ -228,6 +228,16 @@ XB_API int xb_comm_synchronize(xb_comm *comm);
 /* Makes every stream of ctx wait for `hip_event` (a hipEvent_t passed as void *) -- the edge xb_comm_fence uses. */
 XB_API int xb_stream_wait_event(xb_ctx *ctx, void *hip_event);
 
+/* ---- host-side scoring used by `bonito evaluate` -----------------------------------------------------------------
+ * util.accuracy(ref, seq, balanced, min_coverage) (util.py:402-424): Smith-Waterman local alignment of the called sequence
+ * against its reference (gap open 8 / extend 4, match +5 / mismatch -4) and '=' / ('=' + 'I' + 'X' + 'D') * 100 from its trace
+ * (balanced: ('=' - 'I') / ('=' + 'X' + 'D')); 0 when less than min_coverage of the reference is aligned.  A restatement of
+ * the parasail call the reference makes (parasail is in no image): see csrc/xb_align.hip for the two stated choices.  Pure host
+ * code, no context needed.  counts (optional) receives the numbers of '=', 'X', 'I', 'D' columns.
+ */
+XB_API int xb_align_accuracy(const char *ref, int ref_len, const char *seq, int seq_len, double min_coverage, int balanced,
+                             double *accuracy, int32_t counts[4]);
+
 /* ---- introspection / measurement ---------------------------------------------------------- */
 
 enum { XB_STAGE_CONV = 0, XB_STAGE_LSTM_IN = 1, XB_STAGE_LSTM_REC = 2, XB_STAGE_LINEAR = 3,

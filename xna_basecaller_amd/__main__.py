@@ -1,8 +1,9 @@
-"""`python -m xna_basecaller_amd basecaller MODEL_DIR READS_DIR ...` == `bonito basecaller ...` (bonito/__init__.py:10-33)."""
+"""`python -m xna_basecaller_amd basecaller MODEL_DIR READS_DIR ...` == `bonito basecaller ...`, and `... evaluate MODEL_DIR
+--directory CTC_DATA` == `bonito evaluate ...` (bonito/__init__.py:10-33)."""
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
 from . import __version__
-from .cli import basecaller
+from .cli import basecaller, evaluate
 
 
 def main():
@@ -13,6 +14,8 @@ def main():
     sub.required = True
     p = sub.add_parser("basecaller", parents=[basecaller.argparser()])
     p.set_defaults(func=basecaller.main)
+    p = sub.add_parser("evaluate", parents=[evaluate.argparser()])
+    p.set_defaults(func=evaluate.main)
     args = parser.parse_args()
     args.func(args)
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "xb_get_stage_times", "xb_reset_stage_times", "xb_geometry", "xb_version", "xb_result_stream",
     "xb_submit_chunks", "xb_collect_chunks", "xb_ctc_logz", "xb_ctc_alignments",
     "xb_comm_unique_id", "xb_comm_create", "xb_comm_destroy", "xb_comm_rank", "xb_comm_world", "xb_comm_last_error",
-    "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event",
+    "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event", "xb_align_accuracy",
 ]
 XB_COMM_ID_BYTES = 128
 
@@ -90,6 +90,7 @@ def load():
     lib.xb_comm_fence.argtypes = [vp, vp, ip]
     lib.xb_comm_synchronize.argtypes = [vp]
     lib.xb_stream_wait_event.argtypes = [vp, vp]
+    lib.xb_align_accuracy.argtypes = [C.c_char_p, ip, C.c_char_p, ip, C.c_double, ip, C.POINTER(C.c_double), vp]
     lib.xb_ctc_logz.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp, vp]
     lib.xb_ctc_alignments.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp]
     lib.xb_submit_chunks.argtypes = [vp, ip, vp, ip, C.c_char_p]
@@ -102,6 +103,17 @@ def load():
     lib.xb_geometry.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
     _lib = lib
     return lib
+
+
+def align_accuracy(ref, seq, balanced=False, min_coverage=0.0, want_counts=False):
+    """util.accuracy (util.py:402-424) through xb_align_accuracy: percent identity of the local alignment, 0 below min_coverage."""
+    r, q = ref.encode("ascii"), seq.encode("ascii")
+    acc = C.c_double()
+    counts = (C.c_int32 * 4)()
+    rc = load().xb_align_accuracy(r, len(r), q, len(q), float(min_coverage), int(bool(balanced)), C.byref(acc), counts)
+    if rc:
+        raise XbError(rc, "xb_align_accuracy: bad argument")
+    return (acc.value, dict(zip("=XID", counts))) if want_counts else acc.value
 
 
 def device_count():

@@ -55,6 +55,18 @@ def mean_qscore_from_qstring(qstring):
     return -10 * np.log10(max(mean_err, 1e-4))
 
 
+def decode_ref(encoded, labels):
+    """Integer-coded reference -> string, blanks removed (util.py:134-138)."""
+    return "".join(labels[e] for e in encoded if e)
+
+
+def accuracy(ref, seq, balanced=False, min_coverage=0.0):
+    """Percent identity of the local alignment of `seq` against `ref` (util.py:402-424); the alignment itself is the
+    library's host-side restatement of the reference's parasail call (xb_align_accuracy)."""
+    from . import _lib
+    return _lib.align_accuracy(ref, seq, balanced=balanced, min_coverage=min_coverage)
+
+
 def column_to_set(filename, idx=0, skip_header=False):
     """
     The set of whitespace-separated field `idx` over the lines of `filename` (read-id lists);
