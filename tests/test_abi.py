@@ -60,3 +60,15 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libxna_oracle" not in src, f
                 assert not [l for l in src.splitlines() if l.lstrip().startswith("#include") and "oracle" in l], f
+
+
+def test_gemm4p_main_loop_isa_audit():
+    """The product GEMM's weight loads are inline asm with hand-counted waits: tools/check_gemm_isa.py compiles the kernels for
+    gfx950 (no GPU needed) and checks every instantiation's main loop for what would break that -- register copies between load
+    and wait, compiler-inserted vmcnt waits or branches, spills."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm_isa.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": ok ") == 9, out.stdout

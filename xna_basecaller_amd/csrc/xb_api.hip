@@ -77,6 +77,7 @@ struct xb_ctx {
     // projections also as hi-only images for XB_PREC_F16F8_IN1
     unsigned char *w3_f4 = nullptr, *wih_f4[5] = {}, *wih_f4h[5] = {}, *wl_f4 = nullptr;
     size_t w3_ks = 0, wih_ks = 0, wih_ksh = 0, wl_ks = 0;
+    int gemm_sn = 0;                           // XB_GEMM_SN: N tiles per XCD super-tile of gemm4p_kernel (0 = gemm_super_n's rule; experiments)
     int gemm_shadow_kernel = 0;                // XB_GEMM_SHADOW: 0 auto (by batch size), 4 gemm4p_kernel, 8 gemm8r_kernel for the slabs beside the recurrence
     int gemm_shadow_wgs = 2;                   // XB_GEMM_SHADOW_WGS=1: GEMM slabs beside the recurrence run one workgroup per CU
     int gemm4 = 1;                             // XB_GEMM4=0: gemm8r_kernel (one workgroup per CU) instead of gemm4p_kernel (A/B comparisons)
@@ -346,6 +347,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = precision_nsplit(ctx);
     g.ldc = ng.ldc; g.out_f32 = ng.out + r0 * ng.ldc;
     g.one_per_cu = shadow && ctx->gemm_shadow_wgs == 1;
+    g.sn = ctx->gemm_sn;
     // which kernel: gemm4p_kernel, except for the slabs that run beside the two-groups-per-workgroup recurrence of a batch
     // above 1024 chunks, where the one-workgroup-per-CU gemm8r_kernel disturbs the recurrence less (same box, ms per step at
     // batch 2048: 477 vs 488 (gemm4p, one workgroup per CU) vs 499; batch 1024: 240 vs 246 vs 235; batch 512: 126.7 vs 129.7 vs
@@ -640,6 +642,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
     if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
     if (const char *e = getenv("XB_GEMM4")) ctx->gemm4 = atoi(e) != 0;
+    if (const char *e = getenv("XB_GEMM_SN")) ctx->gemm_sn = atoi(e) > 0 && atoi(e) <= 64 ? atoi(e) : 0;
     if (const char *e = getenv("XB_GEMM_SHADOW_WGS")) ctx->gemm_shadow_wgs = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("XB_GEMM_SHADOW")) ctx->gemm_shadow_kernel = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
 

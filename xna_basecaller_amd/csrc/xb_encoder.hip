@@ -188,10 +188,17 @@ constexpr int GBM = 256, GBN = 256, GBK = 32, GTHREADS = 512;
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b & 7), each with its own
 // L2.  The 32 blocks an XCD runs side by side are made one super-tile of SM x SN output tiles, so an A row panel is
 // fetched by SN neighbours and a B panel by SM neighbours out of the SAME L2 instead of by all eight.
+// N tiles per XCD super-tile (both GEMM kernels).  Two (three where the tile count is odd and a multiple of three): the weight
+// panels an XCD works on at a time then stay in its 4 MiB L2 beside the streaming A panels, and every super-tile is full -- four
+// (round 2) left the CRF linear layer's (6 tiles of 256) and conv3's (3 tiles) last super-tile half empty.  Measured with
+// gemm4p_kernel, ms per step at batch 512, overlapped: 120.1 (two or three) vs 122.8 (four) vs 123.3 / 125.5 (six / twelve);
+// linear layer alone 5.7 vs 6.9 ms (profiles/r03_gemm_supertile_width.txt).
+__host__ __device__ inline int gemm_super_n(int NT) { return NT % 2 == 0 ? 2 : (NT % 3 == 0 ? 3 : 1); }
+
 __device__ __forceinline__ bool gemm_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
 {
     const int MT = (p.M + GBM - 1) / GBM, NT = (p.Nn + GBN - 1) / GBN;
-    const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
+    const int SN = gemm_super_n(NT), SM = 32 / SN;
     const int ngroups = (NT + SN - 1) / SN, msup = (MT + SM - 1) / SM;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int q = (j >> 5) * 8 + xcd, w = j & 31;          // super-tile id, slot in it
@@ -263,6 +270,21 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
                     for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
                 }
         }
+        return;
+    }
+    if (EPI == xb::EPI_TANH_SCALE && interior && !p.expand) {
+        // interior wave tile of the CRF linear layer without the blank column (the fused path's layout): rows ldc apart, no
+        // bounds checks, no per-element column arithmetic
+        float *tile = p.out_f32 + (size_t)mw * p.ldc + nw;
+        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rowp[loff + j * 32] = p.scale * fast_tanh(acc[i][j][r] + bj[j]);
+            }
         return;
     }
     if (EPI == xb::EPI_SILU_SPLIT && interior) {
@@ -610,11 +632,13 @@ constexpr int G4_BM = 128, G4_BN = 256, G4_THREADS = 256;
 __device__ __forceinline__ bool gemm4_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
 {
     const int MT = (p.M + G4_BM - 1) / G4_BM, NT = (p.Nn + G4_BN - 1) / G4_BN;
-    const int SN = NT < 4 ? NT : 4, SM = 64 / SN;            // 64 workgroups per XCD side by side (two per CU)
+    const int snw = p.sn > 0 ? p.sn : gemm_super_n(NT);
+    const int SN = NT < snw ? NT : snw, SM = 64 / SN;        // 64 workgroups per XCD side by side (two per CU)
     const int ngroups = (NT + SN - 1) / SN, msup = (MT + SM - 1) / SM;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int q = (j >> 6) * 8 + xcd, w = j & 63;            // super-tile id, slot in it
     if (q >= msup * ngroups || w >= SM * SN) return false;
+    // neighbouring slots share an A panel (giving it to slots SM apart instead measured 121.8 vs 118.9 ms per step)
     const int mt = (q / ngroups) * SM + w / SN, nt = (q % ngroups) * SN + w % SN;
     if (mt >= MT || nt >= NT) return false;
     m0 = mt * G4_BM;
@@ -667,6 +691,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     const size_t bks = p.b4_kstride;
     const unsigned voff0 = (unsigned)lane * 16, voff1 = voff0 + NPC * 1024;
     u32x4 bE[2][NPC], bO[2][NPC];               // even / odd k-tile
+    // (default cache policy: with the nt bit -- the weights bypassing the L1 -- the five input GEMMs take 65 instead of 47 ms)
 #define G4P_LDB(dst, base, j, pc)                                                               \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"((j) ? voff1 : voff0), "s"(base), "i"((pc) * 1024))
 #define G4P_LDB_GROUP(bS, base, pc)                                                             \
@@ -1619,7 +1644,7 @@ template <int EPI, int NSPLIT>
 hipError_t launch_gemm_ns(const xb::GemmParams &p, hipStream_t stream)
 {
     const int MT = (p.M + GBM - 1) / GBM, NT = (p.Nn + GBN - 1) / GBN;
-    const int SN = NT < 4 ? NT : 4, SM = 32 / SN;
+    const int SN = gemm_super_n(NT), SM = 32 / SN;
     const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see gemm_tile_origin
     dim3 grid(8 * 32 * ((supers + 7) / 8)), block(GTHREADS);
     const size_t lds = (size_t)2 * 4 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;    // [4 half-tiles][2 buffers][parts][128 rows x 64 B]
@@ -1633,7 +1658,8 @@ template <int EPI, int NSPLIT>
 hipError_t launch_gemm4p_ns(const xb::GemmParams &p, hipStream_t stream)
 {
     const int MT = (p.M + G4_BM - 1) / G4_BM, NT = (p.Nn + G4_BN - 1) / G4_BN;
-    const int SN = NT < 4 ? NT : 4, SM = 64 / SN;
+    const int snw = p.sn > 0 ? p.sn : gemm_super_n(NT);
+    const int SN = NT < snw ? NT : snw, SM = 64 / SN;
     const int supers = ((NT + SN - 1) / SN) * ((MT + SM - 1) / SM);     // see gemm4_tile_origin
     dim3 grid(8 * 64 * ((supers + 7) / 8)), block(G4_THREADS);
     size_t lds = (size_t)3 * (NSPLIT == 1 ? 1 : 2) * 128 * 64;             // [3 stages][parts][128 rows x 64 B]

@@ -94,6 +94,7 @@ struct GemmParams {
     const unsigned char *b4;     // [K / 32][rows4 / 32][pieces][64 lanes][16 B], rows4 = Nn rounded up to 256 (zero rows)
     size_t b4_kstride;           // bytes between consecutive k-tiles of b4 = rows4 / 32 * pieces * 1024
     int one_per_cu;              // gemm4p: 1 = at most one workgroup per CU (launches beside the recurrence)
+    int sn;                      // gemm4p: N tiles per XCD super-tile (0 = the rule gemm_super_n; XB_GEMM_SN, experiments)
 };
 // pieces per 32-row block and k-tile of the fragment-major image for a given nsplit (lane l = 32 h + r holds row r):
 //   piece 0, 1: the 8 fp16 `hi` values of columns 32 kt + 16 ks + 8 h .. + 8, ks = 0, 1
