@@ -17,6 +17,8 @@ from .oracle import (  # noqa: F401
     decode_batch,
     ctc_indices,
     ctc_logz,
+    beam_search,
+    log_beam_cut,
     conv1d_silu,
     lstm,
     linear_crf,

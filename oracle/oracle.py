@@ -48,6 +48,7 @@ def lib():
         _lib.xo_encode.restype = C.c_int
         _lib.xo_num_threads.restype = C.c_int
         _lib.xo_ctc_logz.restype = C.c_int
+        _lib.xo_beam_search.restype = C.c_int
     return _lib
 
 
@@ -301,4 +302,31 @@ def ctc_logz(scores, targets, target_lengths, n_base, state_len, semiring="log",
         out["stay"] = gs
         if gm is not None:
             out["move"] = gm
+    return out
+
+
+def log_beam_cut(beam_cut):
+    """log(beam_cut) as the float both sides use (FLT_MAX switches the cut off, as in the published decoder)."""
+    import math
+    return float(np.float32(math.log(beam_cut))) if beam_cut > 0 else float(np.finfo(np.float32).max)
+
+
+def beam_search(scores, alphabet, state_len, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=None):
+    """
+    koi.decode.beam_search as called at crf/basecall.py:43-46, restated (xna_oracle.c: "CRF beam search"; parity unpinned).
+    scores (T, N, C) fp32 with or without the blank column.  Returns dict: 'sequence', 'qstring' (N, T) int8 (ASCII at the
+    emitting blocks, 0 elsewhere), 'moves' (N, T) uint8, 'score' (N,) float32.
+    """
+    n_base = len(alphabet) - 1
+    scores, T, N, S, E, has_blank, blank = _decode_args(scores, n_base, state_len, blank_score)
+    d = decode(scores, n_base, state_len, blank_score=blank_score, want=("alpha", "beta", "logz"))
+    out = {"sequence": np.zeros((N, T), dtype=np.int8), "qstring": np.zeros((N, T), dtype=np.int8),
+           "moves": np.zeros((N, T), dtype=np.uint8), "score": np.zeros((N,), dtype=np.float32)}
+    rc = lib().xo_beam_search(_p(scores), C.c_int(T), C.c_int(N), C.c_int(n_base), C.c_int(state_len), C.c_int(has_blank),
+                              C.c_float(blank), _p(d["alpha"]), _p(d["beta"]), _p(d["logz"]), C.c_int(int(beam_width)),
+                              C.c_float(log_beam_cut(beam_cut)), C.c_float(scale), C.c_float(offset),
+                              C.c_char_p(alphabet.encode("ascii")), _p(out["sequence"], i8p), _p(out["qstring"], i8p),
+                              out["moves"].ctypes.data_as(C.POINTER(C.c_uint8)), _p(out["score"]))
+    if rc:
+        raise ValueError("xo_beam_search failed (%d)" % rc)
     return out

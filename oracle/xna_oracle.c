@@ -999,6 +999,248 @@ XO_API int xo_ctc_logz(const float *scores, int T, int N, int C, const int32_t *
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* CRF beam search with qualities and moves (the non-Viterbi branch of compute_scores,   */
+/* crf/basecall.py:33-46: koi.decode.beam_search(scores, beam_width=32, beam_cut=100,     */
+/* scale, offset, blank_score=2.0) -> sequence, qstring, moves)                           */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * koi 0.0.5 is not in /root/reference (a pip dependency, CUDA only) and the reference holds no vectors for it: PARITY
+ * UNPINNED.  What is restated here is the algorithm ONT publishes for this decoder (the open CPU decoder of its production
+ * basecaller, decode/beam_search.cpp, which mirrors koi's kernels), generalised from 4 bases / power-of-two k-mers to the
+ * n_base-ary state table of crf/model.py:31-36 and put on this file's arithmetic contract (xo_expf_i / xo_logf_i, no
+ * contraction), so that the HIP kernel can be checked bit for bit:
+ *
+ *   back guide   beta (T+1, N, S): the Log-semiring backward scores of the contract above (xo_decode), stay score = the
+ *                blank column (or the constant `blank`).
+ *   beam element (hash, state, prev element, stay flag) + score (log-sum over merged paths, WITHOUT the back guide).
+ *   start        every state whose beta_0 is among the beam_width best ((beam_width+1)-th largest value as threshold, states
+ *                in ascending order, at most beam_width), hash = crc32c(seed, state), score 0.
+ *   block t      candidates in this order: for every element p (beam order) and base b the step into
+ *                j = (state % nb^(sl-1)) * nb + b with score (s_p + M[t, j, 1 + state / nb^(sl-1)]) + beta_{t+1}[j] and hash
+ *                crc32c(hash_p, j); then for every element p the stay, (s_p + M[t, state, 0]) + beta_{t+1}[state], same hash.
+ *                A stay whose hash equals that of a step into the same latest base (the same base sequence reached by
+ *                a move) is merged with it: the better of the two keeps lse2(a, b), the other gets -FLT_MAX.
+ *                Kept: the first beam_width candidates, in candidate order, whose score reaches max - log(beam_cut); if more
+ *                than beam_width reach it the threshold is bisected between it and the maximum (at most 10 guesses, a
+ *                count in [0.8 beam_width, beam_width] stops the search, after 10 guesses the upper limit is taken).
+ *                The back guide is subtracted again from the kept scores.  After the last block the best element
+ *                (first maximum) is element 0.
+ *   trace back   from element 0 of the last block: state and stay flag per block; moves[0] = 1.
+ *   qualities    per block the posterior mass of the path k-mer and of its nb left- and nb right-shifted neighbours at t+1,
+ *                P_t(s) = exp((alpha_t[s] + beta_t[s]) - logZ), clamped to [0, 1], raised to 0.4; a base's probability is the
+ *                mean over the blocks it spans (sum of p over sum of (p + (nb-1) * (1-p)/(nb-1))); q = -10 log10(1 - prob)
+ *                * qscale + qoffset, clamped to [1, 50], character (int)(33.5 + q).
+ *   outputs      sequence (N, T) int8: alphabet[1 + base] at the blocks that emit (moves = 1), else 0; qstring (N, T) int8 the
+ *                quality character at the same blocks; moves (N, T) uint8; score (N) the path score of element 0 [optional].
+ */
+#define XO_BEAM_MAX 32
+#define XO_CRC_SEED 0x12345678u
+#define XO_HASH_BITS 4096
+
+static inline uint32_t xo_crc32c_u32(uint32_t crc, uint32_t v)
+{
+    crc ^= v;
+    for (int i = 0; i < 32; ++i) crc = (crc >> 1) ^ (0x82F63B78u & (0u - (crc & 1u)));
+    return crc;
+}
+
+static inline float xo_lse2(float x, float y)
+{
+    const float d = fabsf(x - y);
+    const float m = x > y ? x : y;
+    return d < 17.0f ? m + xo_logf_i(1.0f + xo_expf_i(-d)) : m;
+}
+
+static int xo_cmp_desc(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x > y ? -1 : (x < y ? 1 : 0);
+}
+
+XO_API int xo_beam_search(const float *scores, int T, int N, int nb, int sl, int has_blank, float blank,
+                          const float *alpha, const float *beta, const float *logz,
+                          int beam_width, float log_beam_cut, float qscale, float qoffset, const char *alphabet,
+                          int8_t *sequence, int8_t *qstring, uint8_t *moves, float *score_out)
+{
+    const int S = (int)ipow(nb, sl), E = nb + 1;
+    const int Cin = has_blank ? S * E : S * nb;
+    const int hi = (int)ipow(nb, sl - 1);
+    const int W = beam_width;
+    if (W < 1 || W > XO_BEAM_MAX || T < 1) return -3;
+    int err = 0;
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int n = 0; n < N; ++n) {
+        uint32_t fh[XO_BEAM_MAX], ch[XO_BEAM_MAX * 8];
+        int fs[XO_BEAM_MAX], cs[XO_BEAM_MAX * 8], cp[XO_BEAM_MAX * 8];
+        uint8_t cstay[XO_BEAM_MAX * 8], present[XO_HASH_BITS];
+        float fsc[XO_BEAM_MAX], csc[XO_BEAM_MAX * 8];
+        /* history: state, prev, stay per (block, element) */
+        int32_t *hst = (int32_t *)malloc(sizeof(int32_t) * (size_t)(T + 1) * W);
+        uint8_t *hprev = (uint8_t *)malloc((size_t)(T + 1) * W), *hstay = (uint8_t *)malloc((size_t)(T + 1) * W);
+        int32_t *path = (int32_t *)malloc(sizeof(int32_t) * (size_t)T);
+        float *prob = (float *)malloc(sizeof(float) * (size_t)T);
+        float *sorted = (float *)malloc(sizeof(float) * (size_t)S);
+        if (!hst || !hprev || !hstay || !path || !prob || !sorted) {
+            err = -1;
+            free(hst); free(hprev); free(hstay); free(path); free(prob); free(sorted);
+            continue;
+        }
+#define BETA(t, s) beta[((size_t)(t) * N + n) * S + (s)]
+#define ALPHA(t, s) alpha[((size_t)(t) * N + n) * S + (s)]
+        /* ---- start ---- */
+        float thr = -3.402823466e+38f;
+        if (W < S) {
+            for (int s_ = 0; s_ < S; ++s_) sorted[s_] = BETA(0, s_);
+            qsort(sorted, (size_t)S, sizeof(float), xo_cmp_desc);
+            thr = sorted[W];
+        }
+        int Wc = 0;
+        for (int s_ = 0; s_ < S && Wc < W; ++s_)
+            if (BETA(0, s_) >= thr) {
+                fh[Wc] = xo_crc32c_u32(XO_CRC_SEED, (uint32_t)s_);
+                fs[Wc] = s_;
+                fsc[Wc] = 0.0f;
+                hst[Wc] = s_; hprev[Wc] = 0; hstay[Wc] = 0;
+                ++Wc;
+            }
+        /* ---- blocks ---- */
+        for (int t = 0; t < T; ++t) {
+            const float *row = scores + ((size_t)t * N + n) * Cin;
+            float max_score = -3.402823466e+38f;
+            memset(present, 0, sizeof(present));
+            int nc = 0;
+            for (int p = 0; p < Wc; ++p)
+                for (int b = 0; b < nb; ++b) {
+                    const int j = (fs[p] % hi) * nb + b, k = fs[p] / hi;
+                    const float m = has_blank ? row[(size_t)j * E + 1 + k] : row[(size_t)j * nb + k];
+                    const float v = (fsc[p] + m) + BETA(t + 1, j);
+                    const uint32_t h = xo_crc32c_u32(fh[p], (uint32_t)j);
+                    present[h % XO_HASH_BITS] = 1;
+                    ch[nc] = h; cs[nc] = j; cp[nc] = p; cstay[nc] = 0; csc[nc] = v;
+                    max_score = v > max_score ? v : max_score;
+                    ++nc;
+                }
+            for (int p = 0; p < Wc; ++p) {
+                const int st = fs[p];
+                const float m = has_blank ? row[(size_t)st * E] : blank;
+                const float v = (fsc[p] + m) + BETA(t + 1, st);
+                const int si = nc;
+                ch[si] = fh[p]; cs[si] = st; cp[si] = p; cstay[si] = 1; csc[si] = v;
+                max_score = v > max_score ? v : max_score;
+                if (present[fh[p] % XO_HASH_BITS]) {
+                    const int latest = st % nb;
+                    for (int q = 0; q < Wc; ++q) {
+                        const int ti = q * nb + latest;
+                        if (ch[si] == ch[ti]) {
+                            const float f = xo_lse2(csc[si], csc[ti]);
+                            if (csc[si] > csc[ti]) { csc[si] = f; csc[ti] = -3.402823466e+38f; }
+                            else { csc[ti] = f; csc[si] = -3.402823466e+38f; }
+                            max_score = f > max_score ? f : max_score;
+                        }
+                    }
+                }
+                ++nc;
+            }
+            float cutoff = max_score - log_beam_cut;
+            int count = 0;
+#define XO_COUNT() do { count = 0; for (int c_ = 0; c_ < nc; ++c_) count += csc[c_] >= cutoff; } while (0)
+            XO_COUNT();
+            if (count > W) {
+                const int minw = (W * 8) / 10;
+                float lo = cutoff, hi_s = max_score;
+                int guesses = 1;
+                while ((count > W || count < minw) && guesses < 10) {
+                    if (count > W) { lo = cutoff; cutoff = (cutoff + hi_s) / 2.0f; }
+                    else { hi_s = cutoff; cutoff = (cutoff + lo) / 2.0f; }
+                    XO_COUNT();
+                    ++guesses;
+                }
+                if (guesses == 10) { cutoff = hi_s; XO_COUNT(); }
+                count = count < W ? count : W;
+            }
+#undef XO_COUNT
+            int w = 0;
+            for (int c = 0; c < nc && w < W; ++c)
+                if (csc[c] >= cutoff) {
+                    fh[w] = ch[c]; fs[w] = cs[c]; fsc[w] = csc[c];
+                    hst[(size_t)(t + 1) * W + w] = cs[c]; hprev[(size_t)(t + 1) * W + w] = (uint8_t)cp[c];
+                    hstay[(size_t)(t + 1) * W + w] = cstay[c];
+                    ++w;
+                }
+            Wc = w;
+            if (t == T - 1) {       /* the best element becomes element 0 (first maximum) */
+                int best = 0;
+                for (int i = 1; i < Wc; ++i) if (fsc[i] > fsc[best]) best = i;
+                if (best != 0) {
+                    const size_t o = (size_t)T * W;
+                    uint32_t th = fh[0]; fh[0] = fh[best]; fh[best] = th;
+                    int ts = fs[0]; fs[0] = fs[best]; fs[best] = ts;
+                    float tf = fsc[0]; fsc[0] = fsc[best]; fsc[best] = tf;
+                    int32_t a = hst[o]; hst[o] = hst[o + best]; hst[o + best] = a;
+                    uint8_t u = hprev[o]; hprev[o] = hprev[o + best]; hprev[o + best] = u;
+                    u = hstay[o]; hstay[o] = hstay[o + best]; hstay[o + best] = u;
+                }
+            }
+            for (int i = 0; i < Wc; ++i) fsc[i] -= BETA(t + 1, fs[i]);
+        }
+        if (score_out) score_out[n] = fsc[0];
+        /* ---- trace back ---- */
+        uint8_t *mv = moves + (size_t)n * T;
+        int el = 0;
+        for (int t = T; t >= 1; --t) {
+            const size_t a = (size_t)t * W + el;
+            path[t - 1] = hst[a];
+            mv[t - 1] = hstay[a] ? 0 : 1;
+            el = hprev[a];
+        }
+        mv[0] = 1;
+        /* ---- per-block probability of the path k-mer ---- */
+        const float lz = logz[n];
+        for (int t = 0; t < T; ++t) {
+            const int st = path[t];
+#define XO_POST(s) xo_expf_i((ALPHA(t + 1, (s)) + BETA(t + 1, (s))) - lz)
+            float p = XO_POST(st);
+            const int l0 = st / nb, r0 = (st % hi) * nb;
+            for (int b = 0; b < nb; ++b) {
+                p += XO_POST(l0 + hi * b);
+                p += XO_POST(r0 + b);
+            }
+#undef XO_POST
+            p = p > 1.0f ? 1.0f : p;
+            p = p < 0.0f ? 0.0f : p;
+            prob[t] = p > 0.0f ? xo_expf_i(0.4f * xo_logf_i(p)) : 0.0f;
+        }
+        /* ---- sequence and quality string at the emitting blocks ---- */
+        int8_t *sq = sequence + (size_t)n * T, *qs = qstring + (size_t)n * T;
+        for (int t = 0; t < T; ++t) { sq[t] = 0; qs[t] = 0; }
+        for (int t = 0; t < T; ++t) {
+            if (!mv[t]) continue;
+            float bp = 0.0f, tot = 0.0f;
+            for (int u = t; u < T && (u == t || !mv[u]); ++u) {
+                const float p = prob[u], wrong = (1.0f - p) / (float)(nb - 1);
+                bp += p;
+                float one = p;
+                for (int j = 1; j < nb; ++j) one += wrong;
+                tot += one;
+            }
+            const float e = 1.0f - bp / tot;
+            float q = e > 0.0f ? xo_logf_i(e) * -4.3429448190325175f : 3.402823466e+38f;
+            q = q * qscale;
+            q = q + qoffset;
+            q = q < 1.0f ? 1.0f : q;
+            q = q > 50.0f ? 50.0f : q;
+            sq[t] = (int8_t)alphabet[1 + path[t] % nb];
+            qs[t] = (int8_t)(int)(33.5f + q);
+        }
+#undef BETA
+#undef ALPHA
+        free(hst); free(hprev); free(hstay); free(path); free(prob); free(sorted);
+    }
+    return err;
+}
+
 XO_API void xo_set_num_threads(int n)
 {
 #ifdef _OPENMP

@@ -5,6 +5,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
+if [ -z "$SKIP_BENCH" ]; then
 timeout -k 10 300 python bench.py --steps 6 --warmup 2 > $O/bench_nb6.json 2> $O/bench.err
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --nbase 5 --cpu-chunks 0 > $O/bench_nb5.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 > $O/bench_n1024.json 2>> $O/bench.err
@@ -13,6 +14,7 @@ timeout -k 10 300 python bench.py --steps 4 --warmup 2 --weights peaky --cpu-chu
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 448 --cpu-chunks 0 > $O/bench_n448.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 98 --cpu-chunks 0 > $O/bench_n98.json 2>> $O/bench.err
 XB_OVERLAP=0 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --cpu-chunks 0 > $O/bench_nb6_serial.json 2>> $O/bench.err
+fi
 (export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1

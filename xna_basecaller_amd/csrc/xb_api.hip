@@ -59,6 +59,7 @@ struct xb_ctx {
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
     size_t dep_next = 0;
     int overlap = 1, time_slabs = 16;   // XB_OVERLAP / XB_TIME_SLABS (upper bound; a slab is at least 125 steps)
+    int slab_steps = 0;                 // XB_SLAB_STEPS: minimum steps per time slab (default 125)
     mutable std::string err;
     int T = 0, S = 0, hi = 0, O = 0, kp = 0, ld_nb = 0;
     bool weights_ready = false;
@@ -429,7 +430,8 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
         // own slot across launches, so chunk slabs and time slabs combine freely; a larger batch falls back to one launch
         // per chunk slab over all steps with launch-local slots
         const bool global_groups = n <= 64 * bn;
-        int nts = T / 125 < ctx->time_slabs ? T / 125 : ctx->time_slabs;
+        const int min_steps = ctx->slab_steps > 0 ? ctx->slab_steps : 125;
+        int nts = T / min_steps < ctx->time_slabs ? T / min_steps : ctx->time_slabs;
         overlapped = next && ctx->overlap && ctx->stream2 && global_groups && nts >= 2;
         if (!overlapped) nts = 1;
         int launches = 0;
@@ -674,6 +676,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         for (int p = 0; p < 2; ++p) XB_CREATE_HIP(hipEventCreateWithFlags(&ctx->dec_done[p], hipEventDisableTiming));
         if (const char *e = getenv("XB_OVERLAP")) ctx->overlap = atoi(e);   // 0 serial, 1 overlapped, 2 time slabs but serial GEMM (A/B)
         if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
+        if (const char *e = getenv("XB_SLAB_STEPS")) ctx->slab_steps = atoi(e) >= 8 ? atoi(e) : 0;
     }
 
     const size_t N = cfg->max_batch, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
