@@ -147,6 +147,32 @@ XB_API int xb_crf_logz(xb_ctx *ctx, const float *scores, int T, int n, int has_b
 XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, float *d_logz);
 
 /*
+ * Beam search with qualities and moves: the non-Viterbi branch of compute_scores (crf/basecall.py:33-46:
+ * `sequence, qstring, moves = koi.decode.beam_search(scores, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0,
+ * blank_score=2.0)`, selected when the model's last layer has expand_blanks = False).  koi 0.0.5 is not part of the
+ * reference tree; the algorithm restated is the one ONT publishes for this decoder (back-guided beam with CRC-32C sequence
+ * hashes, stay / step merging, beam cut by bisection, k-mer posterior qualities), generalised to n_base in 2..7 -- its
+ * specification is the "CRF beam search" section of oracle/xna_oracle.c, against which the kernel is bit-exact.  PARITY UNPINNED.
+ *   scores    (T, n, C) fp32; has_blank = 0: C = S * n_base and the stay score is the context's blank_score (what the
+ *             reference passes); has_blank = 1: the stay score is column 0 of every state row.
+ *   beam_width 1..32; beam_cut > 0 (candidates below max - log(beam_cut) are dropped; <= 0: no cut); qscale / qoffset =
+ *             koi's scale / offset on the phred value.  States: at most 4096.
+ *   sequence, qstring (n, T) int8: the base character alphabet[1 + base] / the quality character (33 + q, q in 1..50) at the
+ *             blocks that emit a base, 0 elsewhere (koi.decode.to_str drops the zeros); moves (n, T) uint8 1 = a base is
+ *             emitted in this block (moves[0] is always 1); score (n) [optional] the log-sum path score of the result.
+ * xb_basecall_chunks_beam = encoder (no blank column) + beam search without the scores leaving the device.
+ */
+XB_API int xb_beam_search(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, const char *alphabet, int beam_width,
+                          float beam_cut, float qscale, float qoffset, int8_t *sequence, int8_t *qstring, uint8_t *moves,
+                          float *score);
+XB_API int xb_beam_search_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, const char *alphabet,
+                              int beam_width, float beam_cut, float qscale, float qoffset, int8_t *d_sequence,
+                              int8_t *d_qstring, uint8_t *d_moves, float *d_score);
+XB_API int xb_basecall_chunks_beam(xb_ctx *ctx, const float *signal, int n, const char *alphabet, int beam_width,
+                                   float beam_cut, float qscale, float qoffset, int8_t *sequence, int8_t *qstring,
+                                   uint8_t *moves, float *score);
+
+/*
  * The CTC-CRF loss scans (CTC_CRF.ctc_loss and ctc_viterbi_alignments, crf/model.py:102-135: prepare_ctc_scores +
  * seqdist.ctc_simple.logZ_cupy / viterbi_alignments), for `bonito evaluate` / fine-tuning on the same device:
  *   scores  (T, n, S*(n_base+1)) fp32 with the blank column -- ctc_loss passes the NORMALISED scores

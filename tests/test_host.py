@@ -493,6 +493,17 @@ def test_load_model_precedence_and_checkpoint_choice(tmp_path):
         else:
             assert torch.equal(v, new[k])
 
+    assert m.encoder[-1].expand_blanks                      # XNA alphabet: use_koi is dropped, Viterbi (util.py:299-301)
+
+    # 4-base model: use_koi (the CLI's default) selects the beam-search decoder, --no-use-koi the Viterbi one
+    d4 = str(tmp_path / "m4")
+    os.makedirs(d4)
+    cfg4 = make_config(32, labels=("N", "A", "C", "G", "T"))
+    open(os.path.join(d4, "config.toml"), "w").write(toml_lite.dumps(cfg4))
+    torch.save(Model(cfg4).state_dict(), os.path.join(d4, "weights_1.tar"))
+    assert not util.load_model(d4, "cuda:0", use_koi=True).encoder[-1].expand_blanks
+    assert util.load_model(d4, "cuda:0", use_koi=False).encoder[-1].expand_blanks
+
     wide = Model(make_config(64)).state_dict()
     torch.save(wide, os.path.join(d, "weights_11.tar"))
     with pytest.raises((AssertionError, RuntimeError)):

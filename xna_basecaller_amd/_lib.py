@@ -24,6 +24,7 @@ EXPORTS = [
     "xb_submit_chunks", "xb_collect_chunks", "xb_ctc_logz", "xb_ctc_alignments",
     "xb_comm_unique_id", "xb_comm_create", "xb_comm_destroy", "xb_comm_rank", "xb_comm_world", "xb_comm_last_error",
     "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event", "xb_align_accuracy",
+    "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam",
 ]
 XB_COMM_ID_BYTES = 128
 
@@ -92,6 +93,10 @@ def load():
     lib.xb_stream_wait_event.argtypes = [vp, vp]
     lib.xb_align_accuracy.argtypes = [C.c_char_p, ip, C.c_char_p, ip, C.c_double, ip, C.POINTER(C.c_double), vp]
     lib.xb_ctc_logz.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp, vp]
+    fl = C.c_float
+    lib.xb_beam_search.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, ip, fl, fl, fl, vp, vp, vp, vp]
+    lib.xb_beam_search_dev.argtypes = [vp, vp, ip, ip, ip, C.c_char_p, ip, fl, fl, fl, vp, vp, vp, vp]
+    lib.xb_basecall_chunks_beam.argtypes = [vp, vp, ip, C.c_char_p, ip, fl, fl, fl, vp, vp, vp, vp]
     lib.xb_ctc_alignments.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, vp]
     lib.xb_submit_chunks.argtypes = [vp, ip, vp, ip, C.c_char_p]
     lib.xb_collect_chunks.argtypes = [vp, ip, vp, vp]
@@ -276,6 +281,40 @@ class Context:
         self._check(self.lib.xb_basecall_chunks(self.h, signal.ctypes.data, n, "".join(alphabet).encode(),
                                                 seq.ctypes.data, lens.ctypes.data))
         return seq, lens
+
+    # ---- beam search with qualities and moves (koi.decode.beam_search at crf/basecall.py:43-46) ----------
+    def _beam_out(self, n, T):
+        return (np.empty((n, T), dtype=np.int8), np.empty((n, T), dtype=np.int8), np.empty((n, T), dtype=np.uint8),
+                np.empty((n,), dtype=np.float32))
+
+    def beam_search(self, scores, alphabet, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0):
+        """xb_beam_search: scores (T, n, C_noblank | C_blank) -> {'sequence', 'qstring' (n, T) int8, 'moves' (n, T) uint8,
+        'score' (n,)}; the stay score of blank-less scores is the context's blank_score."""
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, n, Cin = scores.shape
+        if Cin not in (self.C_blank, self.C_noblank):
+            raise ValueError("scores last dim %d matches neither %d nor %d" % (Cin, self.C_blank, self.C_noblank))
+        seq, q, mv, sc = self._beam_out(n, T)
+        self._check(self.lib.xb_beam_search(self.h, scores.ctypes.data, T, n, int(Cin == self.C_blank), "".join(alphabet).encode(),
+                                            int(beam_width), float(beam_cut), float(scale), float(offset), seq.ctypes.data,
+                                            q.ctypes.data, mv.ctypes.data, sc.ctypes.data))
+        return {"sequence": seq, "qstring": q, "moves": mv, "score": sc}
+
+    def basecall_chunks_beam(self, signal, alphabet, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0):
+        """xb_basecall_chunks_beam: signal (n, chunk_len) -> the same dict as beam_search, scores never leave the device."""
+        signal = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1, self.chunk_len)
+        n = signal.shape[0]
+        seq, q, mv, sc = self._beam_out(n, self.T)
+        self._check(self.lib.xb_basecall_chunks_beam(self.h, signal.ctypes.data, n, "".join(alphabet).encode(), int(beam_width),
+                                                     float(beam_cut), float(scale), float(offset), seq.ctypes.data, q.ctypes.data,
+                                                     mv.ctypes.data, sc.ctypes.data))
+        return {"sequence": seq, "qstring": q, "moves": mv, "score": sc}
+
+    def beam_search_dev(self, d_scores, T, n, has_blank, alphabet, d_sequence, d_qstring, d_moves, d_score=None, beam_width=32,
+                        beam_cut=100.0, scale=1.0, offset=0.0):
+        self._check(self.lib.xb_beam_search_dev(self.h, _ptr(d_scores), int(T), int(n), int(bool(has_blank)),
+                                                "".join(alphabet).encode(), int(beam_width), float(beam_cut), float(scale),
+                                                float(offset), _ptr(d_sequence), _ptr(d_qstring), _ptr(d_moves), _ptr(d_score)))
 
     # ---- host pipeline: two batches in flight (xb_submit_chunks / xb_collect_chunks) ----------
     def submit_chunks(self, slot, signal, alphabet):

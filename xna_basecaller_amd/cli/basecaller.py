@@ -114,7 +114,7 @@ def main(args):
 
     if args.verbose:
         sys.stderr.write(f"> model basecaller params: {model.config['basecaller']}\n")
-        sys.stderr.write("> decode algorithm: Viterbi\n")
+        sys.stderr.write("> decode algorithm: %s\n" % ("Viterbi" if model.encoder[-1].expand_blanks else "Beam Search"))
         sys.stderr.write(f"> read_ids: {args.read_ids}\n")
 
     basecall = load_symbol(args.model_directory, "basecall")

@@ -8,7 +8,7 @@ from threading import Thread
 
 import numpy as np
 
-from ..util import chunk, stitch, batchify, unbatchify
+from ..util import chunk, stitch, batchify, unbatchify, mean_qscore_from_qstring
 
 
 class _ThreadIterator(Thread):
@@ -52,12 +52,23 @@ def stitch_results(results, length, size, overlap, stride, reverse=False):
 def compute_scores(model, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0, blank_score=2.0,
                    reverse=False):
     """
-    crf/basecall.py:27-82, Viterbi branch (the only one reachable for XNA alphabets): (n,1,L) batch ->
-    {'sequence': int8 (n,T) left-packed ASCII, 'qstring': int8 (n,T) of 'O', 'moves': bool (n,T) all False}.
-    One fused device call; the per-character Python loops of the reference are gone.
+    crf/basecall.py:27-82: (n,1,L) batch -> {'sequence': int8 (n,T), 'qstring': int8 (n,T), 'moves': bool (n,T)}.
+    Viterbi branch (expand_blanks, the only one the reference reaches for XNA alphabets): left-packed ASCII rows, 'O'
+    placeholders, no moves -- one fused device call; the per-character Python loops of the reference are gone.
+    Beam branch (expand_blanks = False, `koi.decode.beam_search`): bases and quality characters at the blocks that emit,
+    real moves -- xb_basecall_chunks_beam, for any alphabet the CRF supports.
     """
     if not model.encoder[-1].expand_blanks:
-        raise NotImplementedError("koi beam search (expand_blanks=False) is not part of the MI355X path")
+        own = model.encoder[-1].blank_score
+        if own is None or float(own) != float(blank_score):
+            raise ValueError("beam search uses the model's fixed blank score (%r); blank_score=%r was asked for"
+                             % (own, blank_score))
+        if reverse:
+            scores = model.seqdist.reverse_complement(model(batch))
+            res = model.beam_search(scores, beam_width, beam_cut, scale, offset)
+        else:
+            res = model.basecall_chunks_beam(batch, beam_width, beam_cut, scale, offset)
+        return {"qstring": res["qstring"], "sequence": res["sequence"], "moves": res["moves"].astype(bool)}
     if reverse:
         scores = model.seqdist.reverse_complement(model(batch))
         ctx = model.context(np.asarray(batch).shape[-1], scores.shape[1])
@@ -105,6 +116,10 @@ def compute_sequences_pipelined(model, batches, reverse=False):
 
 def compute_scores_pipelined(model, batches, reverse=False):
     """compute_scores over a stream of (key, batch), two batches in flight; yields the reference's result dicts."""
+    if not model.encoder[-1].expand_blanks:              # beam search: qualities and moves are real, one batch at a time
+        for key, batch in batches:
+            yield key, compute_scores(model, batch, reverse=reverse)
+        return
     for key, sequence in compute_sequences_pipelined(model, batches, reverse=reverse):
         yield key, _scores_dict(sequence)
 
@@ -139,6 +154,13 @@ def _called(model, sequence):
             "mean_qscore": 40.0 if seq else 0.0}           # = mean_qscore_from_qstring('O' * n), util.py:124-131
 
 
+def _called_beam(model, attrs):
+    """crf/basecall.py:85-93 on stitched beam-search results, plus the mean quality the writers print."""
+    out = apply_stride_to_moves(model, attrs)
+    out["mean_qscore"] = mean_qscore_from_qstring(out["qstring"]) if out["qstring"] else 0.0
+    return out
+
+
 def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=False):
     """Basecall `reads` (objects with .signal); yields (read, {'sequence','qstring','sig_move'}) in input order."""
     chunks = thread_iter(
@@ -146,6 +168,14 @@ def basecall(model, reads, chunksize=4000, overlap=100, batchsize=32, reverse=Fa
         for read in reads
     )
     batches = thread_iter(batchify(chunks, batchsize=batchsize))
+    if not model.encoder[-1].expand_blanks:
+        # the reference's own five stages (crf/basecall.py:96-122): result dicts are unbatched and stitched plane by plane
+        scores = thread_iter(compute_scores_pipelined(model, batches, reverse=reverse))
+        results = thread_iter(
+            (read, stitch_results(attrs, end - start, chunksize, overlap, model.stride, reverse))
+            for ((read, start, end), attrs) in unbatchify(scores)
+        )
+        return thread_iter((read, _called_beam(model, attrs)) for read, attrs in results)
     sequences = thread_iter(compute_sequences_pipelined(model, batches, reverse=reverse))
     results = thread_iter(
         (read, stitch(seq, chunksize, overlap, end - start, model.stride, reverse=reverse))

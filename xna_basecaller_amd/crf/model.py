@@ -400,6 +400,21 @@ class Model(torch.nn.Module):
         ctx = self.context(sig.shape[1], sig.shape[0])
         return ctx.basecall_chunks(sig, self.alphabet)
 
+    def basecall_chunks_beam(self, batch, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0):
+        """Fused encode + beam search of a (N,1,L) batch -> {'sequence', 'qstring' (N,T) int8, 'moves' (N,T) uint8, 'score'}:
+        koi.decode.beam_search on the model's blank-less scores (crf/basecall.py:33-46), one device call."""
+        sig = self._as_signal(batch)
+        ctx = self.context(sig.shape[1], sig.shape[0])
+        return ctx.basecall_chunks_beam(sig, self.alphabet, beam_width, beam_cut, scale, offset)
+
+    def beam_search(self, scores, beam_width=32, beam_cut=100.0, scale=1.0, offset=0.0):
+        """(T,N,C) host scores (with or without the blank column) -> the same dict."""
+        if hasattr(scores, "detach"):
+            scores = scores.detach().to(torch.float32).cpu().numpy()
+        scores = np.ascontiguousarray(scores, dtype=np.float32)
+        T, N, _ = scores.shape
+        return self.context(T * self.stride, N).beam_search(scores, self.alphabet, beam_width, beam_cut, scale, offset)
+
     def submit_chunks(self, slot, batch):
         """Enqueue the fused encode + decode of a (N,1,L) batch in pipeline slot 0/1 without waiting; returns a handle
         for collect_chunks.  The caller keeps at most one handle per slot in flight."""

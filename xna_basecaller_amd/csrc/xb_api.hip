@@ -95,6 +95,12 @@ struct xb_ctx {
     float *gin = nullptr, *gin2 = nullptr, *c_state = nullptr, *scores = nullptr, *scores2 = nullptr;
     half_t *xh = nullptr;        // LSTM exchange buffer: 64 groups x 2 parity x 2 parts x 64 chunks x F
     float *alpha = nullptr, *beta = nullptr, *bmax = nullptr, *qbuf = nullptr, *logz = nullptr;
+    // beam search workspaces and staging (lazily allocated: most contexts never use them)
+    uint32_t *beam_hist = nullptr;
+    int32_t *beam_path = nullptr;
+    float *beam_prob = nullptr, *beam_score = nullptr;
+    int8_t *beam_seq = nullptr, *beam_q = nullptr;
+    uint8_t *beam_moves = nullptr;
     int8_t *labels = nullptr, *seq = nullptr;
     int32_t *seq_len = nullptr;
     unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
@@ -1098,6 +1104,115 @@ XB_API int xb_ctc_alignments(xb_ctx *ctx, const float *scores, int T, int n, con
 {
     if (!alignments) return fail(ctx, XB_ERR_INVALID, "null host pointer");
     return run_ctc(ctx, scores, T, n, targets, Lt, target_lengths, 1, max_score, alignments, nullptr);
+}
+
+// beam search over device-resident scores: the Log scans (alpha, beta, logZ) into the decode workspaces, then one wave per chunk
+static int run_beam(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, int ld, const char *alphabet, int beam_width,
+                    float beam_cut, float qscale, float qoffset, int8_t *d_seq, int8_t *d_q, uint8_t *d_moves, float *d_score)
+{
+    const xb_config &c = ctx->cfg;
+    if (beam_width < 1 || beam_width > xb::BEAM_MAX_WIDTH)
+        return fail(ctx, XB_ERR_INVALID, "beam_width %d outside [1, %d]", beam_width, xb::BEAM_MAX_WIDTH);
+    if (ctx->S > xb::BEAM_MAX_STATES) return fail(ctx, XB_ERR_INVALID, "beam search supports at most %d states", xb::BEAM_MAX_STATES);
+    if (!alphabet || (int)strlen(alphabet) < c.n_base + 1) return fail(ctx, XB_ERR_INVALID, "alphabet needs %d symbols", c.n_base + 1);
+    if (!ctx->beam_hist) {
+        const size_t N = (size_t)c.max_batch, Tm = (size_t)ctx->T;
+        int rc = dev_alloc(ctx, &ctx->beam_hist, N * (Tm + 1) * xb::BEAM_MAX_WIDTH);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_path, N * Tm);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_prob, N * Tm);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_score, N);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_seq, N * Tm);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_q, N * Tm);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->beam_moves, N * Tm);
+        if (rc) { ctx->beam_hist = nullptr; return rc; }
+    }
+    ScanOut so;
+    so.alpha = ctx->alpha; so.beta = ctx->beta; so.logz = ctx->logz;
+    int rc = run_decode(ctx, d_scores, T, n, has_blank, ld, nullptr, nullptr, nullptr, nullptr, nullptr, &so);
+    if (rc) return rc;
+    xb::BeamParams p{};
+    p.scores = d_scores; p.ld = ld; p.has_blank = has_blank; p.blank = c.blank_score;
+    p.alpha = ctx->alpha; p.beta = ctx->beta; p.logz = ctx->logz;
+    p.T = T; p.N = n; p.S = ctx->S; p.nb = c.n_base; p.hi = ctx->hi;
+    p.W = beam_width;
+    p.log_cut = beam_cut > 0.0f ? (float)log((double)beam_cut) : 3.402823466e+38f;
+    p.qscale = qscale; p.qoffset = qoffset;
+    memset(p.base_chars, 0, sizeof p.base_chars);
+    memcpy(p.base_chars, alphabet + 1, (size_t)c.n_base);
+    p.hist = ctx->beam_hist; p.path = ctx->beam_path; p.prob = ctx->beam_prob;
+    p.seq = d_seq ? d_seq : ctx->beam_seq; p.qstr = d_q ? d_q : ctx->beam_q; p.moves = d_moves ? d_moves : ctx->beam_moves;
+    p.score = d_seq ? d_score : ctx->beam_score;
+    StageScope sc(ctx, XB_STAGE_DECODE, 1, ctx->stream);
+    hipError_t e = xb::launch_beam_search(p, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? XB_ERR_INVALID : XB_ERR_HIP, "beam search launch failed: %s", hipGetErrorString(e));
+    return XB_OK;
+}
+
+XB_API int xb_beam_search_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, const char *alphabet,
+                              int beam_width, float beam_cut, float qscale, float qoffset, int8_t *d_sequence, int8_t *d_qstring,
+                              uint8_t *d_moves, float *d_score)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!d_scores || !d_sequence || !d_qstring || !d_moves) return fail(ctx, XB_ERR_INVALID, "null device pointer");
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = join_async_decode(ctx)) return rc;
+    ctx->result_stream = ctx->stream;
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    return run_beam(ctx, d_scores, T, n, has_blank ? 1 : 0, ld, alphabet, beam_width, beam_cut, qscale, qoffset, d_sequence,
+                    d_qstring, d_moves, d_score);
+}
+
+// the three (n, T) byte planes and the optional path scores back to the host
+static int beam_results_to_host(xb_ctx *ctx, int T, int n, int8_t *sequence, int8_t *qstring, uint8_t *moves, float *score)
+{
+    const size_t nt = (size_t)n * T;
+    XB_HIP(ctx, hipMemcpyAsync(sequence, ctx->beam_seq, nt, hipMemcpyDeviceToHost, ctx->stream));
+    XB_HIP(ctx, hipMemcpyAsync(qstring, ctx->beam_q, nt, hipMemcpyDeviceToHost, ctx->stream));
+    XB_HIP(ctx, hipMemcpyAsync(moves, ctx->beam_moves, nt, hipMemcpyDeviceToHost, ctx->stream));
+    if (score) XB_HIP(ctx, hipMemcpyAsync(score, ctx->beam_score, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return xb_synchronize(ctx);
+}
+
+XB_API int xb_beam_search(xb_ctx *ctx, const float *scores, int T, int n, int has_blank, const char *alphabet, int beam_width,
+                          float beam_cut, float qscale, float qoffset, int8_t *sequence, int8_t *qstring, uint8_t *moves,
+                          float *score)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (!scores || !sequence || !qstring || !moves) return fail(ctx, XB_ERR_INVALID, "null host pointer");
+    if (T < 1 || T > ctx->T) return fail(ctx, XB_ERR_INVALID, "T=%d outside [1, %d]", T, ctx->T);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcj = join_async_decode(ctx)) return rcj;
+    ctx->result_stream = ctx->stream;
+    const int ld = has_blank ? ctx->S * (ctx->cfg.n_base + 1) : ctx->O;
+    XB_HIP(ctx, hipMemcpyAsync(ctx->scores, scores, sizeof(float) * (size_t)T * n * ld, hipMemcpyHostToDevice, ctx->stream));
+    // the first call allocates the staging planes inside run_beam; pass them after the allocation
+    int rc = run_beam(ctx, ctx->scores, T, n, has_blank ? 1 : 0, ld, alphabet, beam_width, beam_cut, qscale, qoffset, nullptr,
+                      nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return beam_results_to_host(ctx, T, n, sequence, qstring, moves, score);
+}
+
+// signal chunks -> encoder (scores without the blank column, as the reference's beam branch sees them) -> beam search
+XB_API int xb_basecall_chunks_beam(xb_ctx *ctx, const float *signal, int n, const char *alphabet, int beam_width, float beam_cut,
+                                   float qscale, float qoffset, int8_t *sequence, int8_t *qstring, uint8_t *moves, float *score)
+{
+    int rc = check_ready(ctx, n);
+    if (rc) return rc;
+    if (!signal || !sequence || !qstring || !moves || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = join_async_decode(ctx))) return rc;
+    ctx->result_stream = ctx->stream;
+    XB_HIP(ctx, hipMemcpyAsync(ctx->d_signal, signal, sizeof(float) * (size_t)n * ctx->cfg.chunk_len, hipMemcpyHostToDevice,
+                               ctx->stream));
+    rc = run_encoder(ctx, ctx->d_signal, n, 0, ctx->scores, ctx->ld_nb);
+    if (rc) return rc;
+    rc = run_beam(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, beam_width, beam_cut, qscale, qoffset, nullptr, nullptr,
+                  nullptr, nullptr);
+    if (rc) return rc;
+    return beam_results_to_host(ctx, ctx->T, n, sequence, qstring, moves, score);
 }
 
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet, int8_t *d_seq,

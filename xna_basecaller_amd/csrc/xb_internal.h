@@ -51,6 +51,31 @@ struct CtcParams {
 hipError_t launch_ctc_scan(const CtcParams &p, hipStream_t stream);
 int ctc_max_positions();
 
+// ---------------------------------------------------------------- beam search (xb_beam.hip)
+// koi.decode.beam_search as compute_scores calls it (crf/basecall.py:43-46): back-guided beam over the CRF with sequence
+// hashes, stay / step merging, qualities from k-mer posteriors, moves.  One wave per chunk.
+constexpr int BEAM_MAX_WIDTH = 32;
+constexpr int BEAM_MAX_STATES = 4096;
+struct BeamParams {
+    const float *scores;         // (T, N, ld) fp32
+    int ld, has_blank;
+    float blank;                 // the stay score when the scores come without the blank column
+    const float *alpha, *beta;   // (T + 1, N, S) Log-semiring scans of the same scores (xb_crf_scans)
+    const float *logz;           // (N)
+    int T, N, S, nb, hi;         // hi = nb^(state_len - 1)
+    int W;                       // beam width, 1..BEAM_MAX_WIDTH
+    float log_cut;               // log(beam_cut), FLT_MAX = no cut
+    float qscale, qoffset;
+    char base_chars[8];          // alphabet[1 + base]
+    uint32_t *hist;              // (N, T + 1, BEAM_MAX_WIDTH) workspace: state | prev << 16 | stay << 24
+    int32_t *path;               // (N, T) workspace: the state of the traced path per block
+    float *prob;                 // (N, T) workspace: per-block probability of the path k-mer
+    int8_t *seq, *qstr;          // (N, T): ASCII at the emitting blocks, 0 elsewhere
+    uint8_t *moves;              // (N, T)
+    float *score;                // (N) or nullptr
+};
+hipError_t launch_beam_search(const BeamParams &p, hipStream_t stream);
+
 // ---------------------------------------------------------------- encoder (xb_encoder.hip)
 
 // conv1(1->4,k5,p2)+SiLU, conv2(4->16,k5,p2)+SiLU, then the im2col rows of conv3

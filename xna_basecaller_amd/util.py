@@ -305,8 +305,8 @@ def load_model(dirname, device, weights=None, half=None, chunksize=None, batchsi
     config.toml + weights_<N>.tar -> Model on `device` (util.py:261-366).  Run parameters:
     command-line flag, else the [basecaller] table, else 4000 / 500 / 64 (a zero chunksize or
     batchsize counts as unset, a zero overlap does not); the newest checkpoint unless
-    `weights` names one; keys remapped by match_names; koi is never used (XNA alphabets have
-    n_base != 4, util.py:299-301).
+    `weights` names one; keys remapped by match_names; `use_koi` selects the beam-search decoder for
+    4-base models with a fixed blank score and is dropped for XNA alphabets (util.py:299-301).
     """
     dirname = _model_dir(dirname)
     checkpoint = _checkpoint_path(dirname, weights)
@@ -326,8 +326,10 @@ def load_model(dirname, device, weights=None, half=None, chunksize=None, batchsi
     if use_koi:
         if model.seqdist.n_base != 4:
             sys.stderr.write("[Warning] Setting use_koi to False because n_base != 4.\n")
-        else:
-            sys.stderr.write("[Warning] koi beam search is not part of the MI355X path; using Viterbi.\n")
+        elif model.encoder[-1].blank_score is not None:
+            # util.py:304-313: koi's encoder hands blank-less scores to koi.decode.beam_search (crf/basecall.py:31-46).  Here the
+            # encoder is the same hand-written one either way; what the flag selects is the decoder: xb_basecall_chunks_beam.
+            model.encoder[-1].expand_blanks = False
 
     skip_layers = []
     if skip_top:
