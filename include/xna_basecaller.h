@@ -156,7 +156,7 @@ XB_API int xb_crf_logz_dev(xb_ctx *ctx, const float *d_scores, int T, int n, int
  *   scores    (T, n, C) fp32; has_blank = 0: C = S * n_base and the stay score is the context's blank_score (what the
  *             reference passes); has_blank = 1: the stay score is column 0 of every state row.
  *   beam_width 1..32; beam_cut > 0 (candidates below max - log(beam_cut) are dropped; <= 0: no cut); qscale / qoffset =
- *             koi's scale / offset on the phred value.  States: at most 4096.
+ *             koi's scale / offset on the phred value.  States: at most 1024 (the limit of the scans).
  *   sequence, qstring (n, T) int8: the base character alphabet[1 + base] / the quality character (33 + q, q in 1..50) at the
  *             blocks that emit a base, 0 elsewhere (koi.decode.to_str drops the zeros); moves (n, T) uint8 1 = a base is
  *             emitted in this block (moves[0] is always 1); score (n) [optional] the log-sum path score of the result.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU tool: time xb_beam_search_dev (Log scans + beam kernel) on device-resident scores at a bench-sized batch.
-  python tools/beam_time.py [N] [nb]"""
+  python tools/beam_time.py [N] [nb] [state_len]"""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ from xna_basecaller_amd import _lib                                          # n
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-sl, T = 3, 2000
+sl = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+T = 2000
 alphabet = "NACGTXY"[:nb + 1]
 ctx = _lib.Context(0, nb, sl, 32, 19, 5, 5.0, 2.0, T * 5, N)
 S = nb ** sl
@@ -29,6 +30,6 @@ for it in range(3):
     ctx.beam_search_dev(sc.data_ptr(), T, N, 0, alphabet, d_seq.data_ptr(), d_q.data_ptr(), d_mv.data_ptr())
     ctx.synchronize()
     dt = time.perf_counter() - t0
-    print("N %d nb %d: scans + beam search %.2f ms  (%.3e samples/s, %.2f bases per block)"
-          % (N, nb, 1e3 * dt, N * T * 5 / dt, float(d_mv.sum()) / (N * T)), flush=True)
+    print("N %d nb %d sl %d: scans + beam search %.2f ms  (%.3e samples/s, %.2f bases per block)"
+          % (N, nb, sl, 1e3 * dt, N * T * 5 / dt, float(d_mv.sum()) / (N * T)), flush=True)
 ctx.close()

@@ -10,7 +10,9 @@
 // blocks of a chunk are strictly sequential, so a chunk is ONE wave (a 64-thread workgroup): no workgroup barriers on the
 // critical path, wave ballots for the counts and the order-preserving compaction, the beam front and the candidate list in
 // LDS.  512 chunks = 512 waves spread over all 256 CUs; the history (state, previous element, stay flag per block and element)
-// goes to HBM and is read back tile by tile for the trace-back.  Scores and back guide are gathered per candidate (L2).
+// goes to HBM and is read back tile by tile for the trace-back.  A block's score row and back-guide row are fetched one block
+// ahead by LDS-DMA (global_load_lds, no staging registers) into a double buffer, so the per-candidate gathers are LDS reads and
+// the rows' HBM latency is off the block's dependency chain (PRE = false: direct gathers, for rows that do not fit in LDS).
 // Floating-point contract as in xb_decode.hip (built with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,14 +32,26 @@ __device__ __forceinline__ int lanes_below(unsigned long long m, int lane)
 {
     return __builtin_popcountll(m & ((1ull << lane) - 1ull));
 }
+// max over the 64 lanes on DPP (one instruction per level; 2 wait states between a VALU write and a DPP read of a register),
+// complete in lane 63 and broadcast from there
 __device__ __forceinline__ float wave_maxf(float v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(v), 63));
 }
 __device__ __forceinline__ int wave_sum(int v)
 {
@@ -45,7 +59,16 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }     // one wave per workgroup: orders the LDS traffic
+// One wave per workgroup: the LDS unit serves a wave's instructions in order, so a write is visible to every later read of the
+// same wave without any wait -- what must not happen is the COMPILER moving an access across the hand-over.  (A __syncthreads()
+// here would also wait for vmcnt(0), i.e. for the rows that were requested for the NEXT block a moment ago.)
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+// the same plus completion of this wave's global stores / loads (history and path written, then read back by other lanes)
+__device__ __forceinline__ void wave_sync_global()
+{
+    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
 
 __device__ __forceinline__ float lse2(float x, float y)
 {
@@ -54,8 +77,20 @@ __device__ __forceinline__ float lse2(float x, float y)
     return d < 17.0f ? m + xb_logf(1.0f + xb_expf(-d)) : m;
 }
 
+__device__ __forceinline__ void dma_to_lds(const float *g, float *lds_wave_base, bool vec16)
+{
+    if (vec16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+
+template <bool PRE>
 __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float pre_smem[];      // PRE: [2][row image | back-guide image]
     __shared__ uint32_t crc_tab[256];
     __shared__ uint32_t f_hash[BW], f_info[BW];
     __shared__ int f_state[BW];
@@ -67,6 +102,7 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
     __shared__ uint32_t keys[xb::BEAM_MAX_STATES];
     __shared__ int t_state[64];
     __shared__ uint8_t t_move[64];
+    __shared__ uint32_t st_tab[xb::BEAM_MAX_STATES];      // per state: leading digit | latest base << 4 | shifted rest * nb << 8
 
     const int lane = threadIdx.x, n = blockIdx.x;
     const int T = p.T, N = p.N, S = p.S, nb = p.nb, hi = p.hi, W = p.W, E = nb + 1;
@@ -80,6 +116,17 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
         crc_tab[i] = c;
     }
+    for (int st = lane; st < S; st += 64) {
+        const int k = st / hi;
+        st_tab[st] = (uint32_t)k | ((uint32_t)(st % nb) << 4) | ((uint32_t)((st - k * hi) * nb) << 8);
+    }
+    int cand_pi[4], cand_b[4];          // step candidate c = q * 64 + lane: element c / nb, base c % nb (the same in every block)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = q * 64 + lane;
+        cand_pi[q] = c / nb;
+        cand_b[q] = c - cand_pi[q] * nb;
+    }
     wave_sync();
     auto crc32c = [&](uint32_t crc, uint32_t v) {
         crc ^= v;
@@ -87,6 +134,25 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
         for (int k = 0; k < 4; ++k) crc = crc_tab[crc & 0xffu] ^ (crc >> 8);
         return crc;
     };
+
+    // row t and back guide t + 1 -> buffer b (exact images: buffer[j] = row[j], buffer[beta_off + s] = beta[s])
+    auto prefetch = [&](int t, int b) {
+        const float *row = p.scores + ((size_t)t * N + n) * p.ld;
+        const float *bt = beta + (size_t)(t + 1) * sstride;
+        float *dst = pre_smem + (size_t)b * p.pre_stride;
+        const int rstep = p.row_vec16 ? 256 : 64, rper = p.row_vec16 ? 4 : 1;
+        for (int i = 0; i < p.row_floats; i += rstep) {
+            const int j = i + lane * rper;
+            if (j < p.row_floats) dma_to_lds(row + j, dst + i, p.row_vec16 != 0);
+        }
+        dst += p.beta_off;
+        const int bstep = p.beta_vec16 ? 256 : 64, bper = p.beta_vec16 ? 4 : 1;
+        for (int i = 0; i < S; i += bstep) {
+            const int j = i + lane * bper;
+            if (j < S) dma_to_lds(bt + j, dst + i, p.beta_vec16 != 0);
+        }
+    };
+    if (PRE) prefetch(0, 0);
 
     // ---- start: the states whose back guide is among the W best
     float thr = NEG_MAX;
@@ -126,31 +192,62 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
     // ---- blocks
     float sc[4];
     for (int t = 0; t < T; ++t) {
-        const float *row = p.scores + ((size_t)t * N + n) * p.ld;
-        const float *b1 = beta + (size_t)(t + 1) * sstride;
+        const float *row, *b1;
+        if (PRE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // block t's images have landed (requested a block ago)
+            wave_sync();
+            row = pre_smem + (size_t)(t & 1) * p.pre_stride;
+            b1 = row + p.beta_off;
+            if (t + 1 < T) prefetch(t + 1, (t + 1) & 1);
+        } else {
+            row = p.scores + ((size_t)t * N + n) * p.ld;
+            b1 = beta + (size_t)(t + 1) * sstride;
+        }
         const int nstep = Wc * nb, nc = nstep + Wc;
+        // every lane builds its (up to) four candidates level by level, so that the four chains of dependent LDS reads
+        // (element -> state table -> score / back guide, and the four CRC table steps) are in flight together
+        {
+            bool isstep[4], valid[4];
+            int pi[4], st[4], j[4];
+            uint32_t tab[4], fh[4], crc[4];
+            float fs[4], m[4], bj[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * 64 + lane;
-            sc[q] = NEG_MAX;
-            if (c < nstep) {
-                const int pi = c / nb, b = c - pi * nb;
-                const int st = f_state[pi];
-                const int k = st / hi, j = (st - k * hi) * nb + b;
-                const float m = p.has_blank ? row[(size_t)j * E + 1 + k] : row[(size_t)j * nb + k];
-                sc[q] = (f_score[pi] + m) + b1[j];
-                c_hash[c] = crc32c(f_hash[pi], (uint32_t)j);
-                c_info[c] = (uint32_t)j | ((uint32_t)pi << 16);
-                c_score[c] = sc[q];
-                claim[c] = -1;
-            } else if (c < nc) {
-                const int pi = c - nstep;
-                const int st = f_state[pi];
-                const float m = p.has_blank ? row[(size_t)st * E] : p.blank;
-                sc[q] = (f_score[pi] + m) + b1[st];
-                c_hash[c] = f_hash[pi];
-                c_info[c] = (uint32_t)st | ((uint32_t)pi << 16) | (1u << 24);
-                c_score[c] = sc[q];
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                isstep[q] = c < nstep;
+                valid[q] = c < nc;
+                pi[q] = isstep[q] ? cand_pi[q] : (valid[q] ? c - nstep : 0);
+                st[q] = f_state[pi[q]];
+                fs[q] = f_score[pi[q]];
+                fh[q] = f_hash[pi[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tab[q] = st_tab[st[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = (int)(tab[q] & 15u);
+                j[q] = isstep[q] ? (int)(tab[q] >> 8) + cand_b[q] : st[q];
+                const int col = p.has_blank ? (isstep[q] ? j[q] * E + 1 + k : st[q] * E) : (isstep[q] ? j[q] * nb + k : 0);
+                m[q] = row[col];
+                bj[q] = b1[j[q]];
+                crc[q] = fh[q] ^ (uint32_t)j[q];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) crc[q] = crc_tab[crc[q] & 0xffu] ^ (crc[q] >> 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 64 + lane;
+                const float mv = (!p.has_blank && !isstep[q]) ? p.blank : m[q];
+                const float v = (fs[q] + mv) + bj[q];
+                sc[q] = valid[q] ? v : NEG_MAX;
+                if (valid[q]) {
+                    c_hash[c] = isstep[q] ? crc[q] : fh[q];
+                    c_info[c] = (uint32_t)j[q] | ((uint32_t)pi[q] << 16) | (isstep[q] ? 0u : 1u << 24);
+                    c_score[c] = v;
+                    if (isstep[q]) claim[c] = -1;
+                }
             }
         }
         wave_sync();
@@ -159,9 +256,11 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
             uint32_t match = 0;
             int latest = 0;
             if (lane < Wc) {
-                latest = f_state[lane] % nb;
+                latest = (int)((st_tab[f_state[lane]] >> 4) & 15u);
                 const uint32_t h = f_hash[lane];
-                for (int j = 0; j < Wc; ++j) match |= (c_hash[j * nb + latest] == h ? 1u : 0u) << j;
+#pragma unroll
+                for (int j = 0; j < BW; ++j)               // all 32 reads in flight at once; elements beyond the front masked out
+                    match |= ((c_hash[(j < Wc ? j : 0) * nb + latest] == h && j < Wc) ? 1u : 0u) << j;
             }
             const unsigned long long any = ballot(match != 0);
             if (any) {
@@ -271,8 +370,7 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
         wave_sync();
     }
     if (p.score && lane == 0) p.score[n] = f_score[0];
-    __threadfence();
-    wave_sync();
+    wave_sync_global();
 
     // ---- trace back, 64 blocks of history per LDS tile
     int32_t *path = p.path + (size_t)n * T;
@@ -300,6 +398,7 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
         }
         wave_sync();
     }
+    wave_sync_global();
 
     // ---- per-block probability of the path k-mer and of its shifted neighbours (posteriors at t + 1)
     const float lz = p.logz[n];
@@ -321,8 +420,7 @@ __global__ __launch_bounds__(64) void beam_kernel(xb::BeamParams p)
             prob[t] = pr > 0.0f ? xb_expf(0.4f * xb_logf(pr)) : 0.0f;
         }
     }
-    __threadfence();
-    wave_sync();
+    wave_sync_global();
 
     // ---- bases and qualities at the emitting blocks
     int8_t *sq = p.seq + (size_t)n * T, *qs = p.qstr + (size_t)n * T;
@@ -363,7 +461,21 @@ hipError_t launch_beam_search(const BeamParams &p, hipStream_t stream)
     if (p.W < 1 || p.W > BEAM_MAX_WIDTH || p.S < 1 || p.S > BEAM_MAX_STATES || p.S > 65535 || p.nb < 2 || p.nb > 7 || p.T < 1 ||
         p.N < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_kernel, dim3(p.N), dim3(64), 0, stream, p);
+    // the double buffer of (score row, back-guide row) images; rows that do not fit are gathered from memory directly
+    BeamParams q = p;
+    const int cin = p.has_blank ? p.S * (p.nb + 1) : p.S * p.nb;
+    q.row_vec16 = (p.ld % 4 == 0 && p.ld >= ((cin + 3) & ~3) && reinterpret_cast<uintptr_t>(p.scores) % 16 == 0) ? 1 : 0;
+    q.beta_vec16 = (p.S % 4 == 0 && reinterpret_cast<uintptr_t>(p.beta) % 16 == 0) ? 1 : 0;
+    q.row_floats = q.row_vec16 ? (cin + 3) & ~3 : cin;
+    q.beta_off = (q.row_floats + 3) & ~3;
+    q.pre_stride = (q.beta_off + p.S + 3) & ~3;
+    const size_t lds = sizeof(float) * 2 * (size_t)q.pre_stride;
+    if (lds <= 96 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&beam_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(beam_kernel<true>, dim3(p.N), dim3(64), lds, stream, q);
+    } else {
+        hipLaunchKernelGGL(beam_kernel<false>, dim3(p.N), dim3(64), 0, stream, q);
+    }
     return hipGetLastError();
 }
 

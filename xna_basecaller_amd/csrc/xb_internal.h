@@ -55,7 +55,7 @@ int ctc_max_positions();
 // koi.decode.beam_search as compute_scores calls it (crf/basecall.py:43-46): back-guided beam over the CRF with sequence
 // hashes, stay / step merging, qualities from k-mer posteriors, moves.  One wave per chunk.
 constexpr int BEAM_MAX_WIDTH = 32;
-constexpr int BEAM_MAX_STATES = 4096;
+constexpr int BEAM_MAX_STATES = 1024;      // = the CRF scans' limit (launch_crf_decode)
 struct BeamParams {
     const float *scores;         // (T, N, ld) fp32
     int ld, has_blank;
@@ -73,6 +73,8 @@ struct BeamParams {
     int8_t *seq, *qstr;          // (N, T): ASCII at the emitting blocks, 0 elsewhere
     uint8_t *moves;              // (N, T)
     float *score;                // (N) or nullptr
+    // filled in by launch_beam_search: the LDS images of a block's score row and back-guide row
+    int row_floats, beta_off, pre_stride, row_vec16, beta_vec16;
 };
 hipError_t launch_beam_search(const BeamParams &p, hipStream_t stream);
 
