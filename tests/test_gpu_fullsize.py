@@ -88,6 +88,26 @@ def test_timed_workload_matches_serial_order_and_oracle(nb, N, monkeypatch):
     assert (lab2 != lab).mean() < 0.5
 
 
+def test_slab_signalling_recurrence_equals_one_launch_per_slab(monkeypatch):
+    """XB_LSTM_SIGNAL=1: ONE recurrence launch per layer that reports its time slabs through a flag word the GEMM stream waits
+    on (hipStreamWaitValue32) -- the default above 512 chunks, forced here at 512 -- against one launch per time slab ordered
+    by events: the same bytes, three batches back to back (the flag keeps counting across layers and batches)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    d_signal = torch.randn((512, L), dtype=torch.float32, device=dev, generator=gen)
+    monkeypatch.delenv("XB_OVERLAP", raising=False)
+    monkeypatch.setenv("XB_LSTM_SIGNAL", "1")
+    ctx, seqs, lens = _run(6, 512, d_signal, 3)
+    ctx.close()
+    assert all(np.array_equal(seqs[0], s) for s in seqs[1:]) and all(np.array_equal(lens[0], l) for l in lens[1:])
+    monkeypatch.setenv("XB_LSTM_SIGNAL", "0")
+    ctx, seqs0, lens0 = _run(6, 512, d_signal, 1)
+    ctx.close()
+    assert np.array_equal(seqs0[0], seqs[0]) and np.array_equal(lens0[0], lens[0])
+
+
 @pytest.mark.parametrize("nb", [5, 6])
 def test_end_to_end_labels_on_the_peaky_model(nb):
     """VERDICT r2 (weak 2 / next 3): with the plain seeded weights the posteriors are flat and the end-to-end comparison above

@@ -1181,6 +1181,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
     }
     bool early = false;     // DUAL: the first piece of the coming group-step was requested during the previous one
+    int sig_i = 0, sig_next = p.sig_flag ? (int)((long long)T / p.sig_nts) : -1;     // slab being worked on, its end step
     for (int s = p.s_begin; s < p.s_end; ++s) {
         const int t = p.reverse ? T - 1 - s : s;
 #pragma unroll 1
@@ -1238,7 +1239,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             }
                         }
                         __syncthreads();
-                        if (*sFlag == 0) return;
+                        if (*sFlag == 0) {
+                            // timed out (the error word is set, the host fails the batch): release the stream that waits for
+                            // this launch's slabs -- a wait on the flag has no timeout of its own
+                            if (tid == 0 && p.sig_flag)
+                                __hip_atomic_fetch_max(p.sig_flag, p.sig_base + (unsigned)p.sig_nts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                            return;
+                        }
                     }
                     XB_STAMP(1);   // gin loads issued + wait for the group
 #pragma unroll
@@ -1565,10 +1572,28 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 const int n = cbase + (to >> 2);
                 if (n <= nlast) {
                     const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
-                    *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
-                    *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+                    if (p.sig_flag) {           // read by another stream's kernel while this launch is still running: write-through
+                        store16_sc1(p.y_hi + o, vhi);
+                        store16_sc1(p.y_lo + o, vlo);
+                    } else {
+                        *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
+                        *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+                    }
                 }
             }
+        }
+        // time slab complete: every wave's output stores are at the coherence point, then one arrival per workgroup; the last
+        // one to arrive publishes the slab to the stream that waits on the flag
+        if (p.sig_flag && s + 1 == sig_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned before = __hip_atomic_fetch_add(p.sig_done + sig_i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1 == (unsigned)(gh * members))          // workgroups beyond the group slots left at the top
+                    __hip_atomic_fetch_max(p.sig_flag, p.sig_base + (unsigned)sig_i + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            ++sig_i;
+            sig_next = (int)((long long)T * (sig_i + 1) / p.sig_nts);
         }
     }
 
@@ -1793,6 +1818,8 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
     if (p.nsplit < 1 || p.nsplit > 5) return hipErrorInvalidValue;
     if (p.nsplit >= 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
+    if (p.sig_flag && (!p.persistent || p.s_begin != 0 || p.s_end != p.T || !p.sig_done || p.sig_nts < 1 || p.sig_nts > p.T))
+        return hipErrorInvalidValue;
     switch (p.F / 16) {
     case 2: return launch_lstm_ks<2>(p, stream);
     case 4: return launch_lstm_ks<4>(p, stream);

@@ -169,6 +169,13 @@ struct LstmParams {
     int slab;                    // index of this launch among the layer's time slabs (selects the byte of the XCD mask below)
     int xcd_local;               // 1: members prove per launch that their group sits on one XCD (words 1..4 of the group's sync
                                  // slot, one byte per time slab, zeroed with the counters) and then exchange h with plain stores
+    // One launch over all steps that reports its time slabs (sig_flag != nullptr): the layer output is stored write-through,
+    // and when the last workgroup has finished slab i (steps [T i / sig_nts, T (i + 1) / sig_nts)) it stores sig_base + i + 1
+    // to *sig_flag -- the word the GEMM stream waits on (hipStreamWaitValue32) before it consumes that slab.
+    unsigned *sig_flag;          // device word, monotonic across layers and batches
+    unsigned *sig_done;          // sig_nts arrival counters, zeroed with the group counters
+    unsigned sig_base;
+    int sig_nts;
 };
 hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // members (workgroups per group) and chunks per group of the LSTM kernel for feature size F
