@@ -953,6 +953,11 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
 // hand-off (stores reaching L2, the other members' arrivals, the poll) then completes while the workgroup runs the other
 // group's step, the first h piece of the coming group-step is requested before the gate math of the current one, and
 // the gin tile is requested a whole group-step ahead: a launch holds twice the chunks at the same residency.
+#ifdef XB_NO_SIGNAL
+#define XB_SIG(x) false
+#else
+#define XB_SIG(x) (x)
+#endif
 template <int KS, int NSPLIT, bool DUAL>
 __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 {
@@ -1181,7 +1186,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
     }
     bool early = false;     // DUAL: the first piece of the coming group-step was requested during the previous one
-    int sig_i = 0, sig_next = p.sig_flag ? (int)((long long)T / p.sig_nts) : -1;     // slab being worked on, its end step
+    int sig_i = 0, sig_next = XB_SIG(p.sig_flag) ? (int)((long long)T / p.sig_nts) : -1;     // slab being worked on, its end step
     for (int s = p.s_begin; s < p.s_end; ++s) {
         const int t = p.reverse ? T - 1 - s : s;
 #pragma unroll 1
@@ -1242,7 +1247,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         if (*sFlag == 0) {
                             // timed out (the error word is set, the host fails the batch): release the stream that waits for
                             // this launch's slabs -- a wait on the flag has no timeout of its own
-                            if (tid == 0 && p.sig_flag)
+                            if (tid == 0 && XB_SIG(p.sig_flag))
                                 __hip_atomic_fetch_max(p.sig_flag, p.sig_base + (unsigned)p.sig_nts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                             return;
                         }
@@ -1572,7 +1577,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 const int n = cbase + (to >> 2);
                 if (n <= nlast) {
                     const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
-                    if (p.sig_flag) {           // read by another stream's kernel while this launch is still running: write-through
+                    if (XB_SIG(p.sig_flag)) {           // read by another stream's kernel while this launch is still running: write-through
                         store16_sc1(p.y_hi + o, vhi);
                         store16_sc1(p.y_lo + o, vlo);
                     } else {
@@ -1584,7 +1589,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         }
         // time slab complete: every wave's output stores are at the coherence point, then one arrival per workgroup; the last
         // one to arrive publishes the slab to the stream that waits on the flag
-        if (p.sig_flag && s + 1 == sig_next) {
+        if (XB_SIG(p.sig_flag) && s + 1 == sig_next) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
