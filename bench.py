@@ -75,6 +75,11 @@ def measured_traffic(kernel_prefix, nb, batch, chunksize, precision):
 
 
 def main():
+    # exactly ONE line on stdout (the contract): libraries that print banners from C (RCCL's version header at the first
+    # communicator) get stderr as their stdout; the JSON line goes to a duplicate of the real one
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -209,7 +214,11 @@ def main():
     flop_launch = 5 * 2.0 * (4 * F) * F * T * N / max(rec_launches / K, 1)   # a layer may run as several time-slab launches
     rec_avg_s = 1e-3 * rec_ms / max(rec_launches, 1)
     rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
-    dual = N > 512 and os.environ.get("XB_LSTM_DUAL", "1") != "0"     # two chunk groups per workgroup
+    # two chunk groups per workgroup: batches above 512 chunks, or two consecutive asynchronous calls of at most
+    # 512 chunks co-scheduled by the library (XB_FUSE) -- visible here as half as many launches as calls
+    chunks_per_launch_factor = 5.0 * K / max(rec_launches, 1)       # calls served per recurrence launch of a layer (time slabs: < 1)
+    fused = chunks_per_launch_factor > 1.5
+    dual = (N > 512 or fused) and os.environ.get("XB_LSTM_DUAL", "1") != "0"
     roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2}[prec], "true" if dual else "false"),
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -220,7 +229,8 @@ def main():
                         "f16f8 one fp16 product + one block-scaled FP8 MFMA (2x rate) for both corrections"}
     # ---- CRF decode: HBM roofline (the north-star target) -------------------------------------------------
     dec_ms, dec_launches = stages["decode"]
-    a_dec = float(T) * N * (3 * S * E * 4 + 7 * S * 4 + 1)        # A_dec bytes per launch
+    # A_dec bytes per launch (a launch decodes the chunks of one call, or of two co-scheduled calls)
+    a_dec = float(T) * N * (3 * S * E * 4 + 7 * S * 4 + 1) * (K / max(dec_launches, 1))
     dec_avg_s = 1e-3 * dec_ms / max(dec_launches, 1)
     dec_gbs = a_dec / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
     roofline_decode = {"kernel": "crf_decode_kernel", "bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
@@ -244,7 +254,11 @@ def main():
                                % ({(5, 512): "1", (6, 512): "2", (6, 1024): "3] per-GPU workload [1 of 8 ranks",
                                    (6, 2048): "4] per-GPU workload [1 of 8 ranks"}.get((nb, N), "-"), nb, S, S * E, L, N, F),
                    "n_base": nb, "chunksize": L, "batch_per_gpu": N, "T": T, "parallelism": "reads sharded x%d" % world,
-                   "collective": ("all_gather of packed sequences per step on a side stream: " + gather_kind) if gather is not None else "none"},
+                   "collective": ("all_gather of packed sequences per step on a side stream: " + gather_kind) if gather is not None else "none",
+                   "in_flight": ("a step = one asynchronous xb_basecall_chunks_dev of %d chunks; the library co-schedules two consecutive "
+                                 "calls through one pass of the encoder and the decode (two chunk groups per recurrence workgroup), "
+                                 "XB_FUSE=0 runs every call on its own" % N) if fused else
+                                "a step = one asynchronous xb_basecall_chunks_dev of %d chunks, each run on its own" % N},
         "roofline": roofline, "roofline_decode": roofline_decode,
         "stage_ms_per_step": {k: v[0] / K for k, v in stages.items()},
         "stage_note": "HIP-event time per stage on its own stream; lstm_in / linear run slab by slab on a second stream "
@@ -253,7 +267,8 @@ def main():
     }
     if world == 1 and args.cpu_chunks > 0:
         out["cpu_baseline"] = cpu_baseline(sd, F, nb, L, args.cpu_chunks, alphabet, args.cpu_repeats)
-    print(json.dumps(out))
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
 
 
 if __name__ == "__main__":

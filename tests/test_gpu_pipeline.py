@@ -108,6 +108,55 @@ def test_pipelined_device_calls_match_blocking_calls():
     ctx.close()
 
 
+def test_two_calls_in_flight_share_one_pass(monkeypatch):
+    """XB_FUSE (default on for contexts of at most 512 chunks): the first of two asynchronous calls is held back and both go
+    through the encoder and the decode as one batch -- half the recurrence launches, the same bytes as with XB_FUSE=0; a held
+    call is launched on its own by xb_result_stream / xb_synchronize / any other entry point, and a lone last call too."""
+    import torch
+    from conftest import encoder_shapes, seeded_state_dict
+    from xna_basecaller_amd import _lib
+
+    F, nb, L, N = 96, 6, 2000, 130
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=3)
+    alphabet = "NACGTXY"
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    d_in = [torch.from_numpy(rng.standard_normal((N, L)).astype(np.float32)).to(dev) for _ in range(5)]
+
+    def run(fuse, poke):
+        monkeypatch.setenv("XB_FUSE", fuse)
+        ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
+        ctx.load_state_dict(sd)
+        d_seq = [torch.full((N, ctx.T), -1, dtype=torch.int8, device=dev) for _ in d_in]
+        d_len = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in d_in]
+        ctx.set_profiling(True)
+        ctx.reset_stage_times()
+        for k, (x, s, l) in enumerate(zip(d_in, d_seq, d_len)):
+            ctx.basecall_chunks_dev(x.data_ptr(), N, alphabet, s.data_ptr(), l.data_ptr())
+            if poke and k == 0:
+                ctx.result_stream()                      # the held call goes out alone; calls 1+2 and 3+4 pair up
+        ctx.synchronize()
+        launches = ctx.stage_times()["decode"][1]
+        out = [(s.cpu().numpy(), l.cpu().numpy()) for s, l in zip(d_seq, d_len)]
+        # a held call is also flushed by an unrelated entry point
+        ctx.basecall_chunks_dev(d_in[0].data_ptr(), N, alphabet, d_seq[0].data_ptr(), d_len[0].data_ptr())
+        sc = ctx.encode(d_in[1].cpu().numpy())
+        assert np.isfinite(sc).all()
+        ctx.synchronize()
+        assert np.array_equal(d_seq[0].cpu().numpy(), out[0][0])
+        ctx.close()
+        return out, launches
+
+    ref, n_ref = run("0", False)
+    got, n_got = run("1", False)
+    poked, n_poked = run("1", True)
+    assert n_ref == 5 and n_got == 3 and n_poked == 3          # (0,1) (2,3) 4  /  0 (1,2) (3,4)
+    for (rs, rl), (gs, gl), (ps, pl) in zip(ref, got, poked):
+        assert np.array_equal(rs, gs) and np.array_equal(rl, gl)
+        assert np.array_equal(rs, ps) and np.array_equal(rl, pl)
+
+
 def test_submit_collect_pipeline_matches_blocking_calls():
     """xb_submit_chunks / xb_collect_chunks: two batches in flight through the pinned staging slots give what the
     blocking entry point gives, in order; slot misuse is an XB_ERR_STATE, not undefined behaviour."""

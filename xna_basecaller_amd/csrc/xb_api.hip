@@ -117,11 +117,34 @@ struct xb_ctx {
     int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
+    // Two asynchronous basecalls in flight are co-scheduled (XB_FUSE, default on for contexts of at most 512 chunks): the first
+    // xb_basecall_chunks_dev of a pair is held back until the second arrives, then both batches go through the encoder and the
+    // decode as ONE batch (the recurrence then runs two chunk groups per workgroup).  Every other entry point,
+    // xb_synchronize and xb_result_stream first launch a held-back call on its own.
+    struct Call {
+        const float *signal = nullptr;
+        int n = 0;
+        char alphabet[16] = {};
+        int8_t *seq = nullptr;
+        int32_t *len = nullptr;
+        int slot = -1;                          // host pipeline slot whose D2H copies and done event follow the launch
+        void (*after)(void *) = nullptr;        // xb_comm: the gather of this call's results, enqueued right behind it
+        void *after_arg = nullptr;
+    };
+    int fuse = 1;
+    int cap = 0;                                // chunks the workspaces hold (2 * max_batch when fusing is possible)
+    Call held;
+    bool holding = false, flushing = false;
+    int8_t *fseq = nullptr;                     // (cap, T) / (cap) results of a fused pair before they are split
+    int32_t *flen = nullptr;
+
     bool profiling = false;
     std::vector<StageEvent> events;
     float stage_ms[XB_STAGE_COUNT] = {};
     int64_t stage_launches[XB_STAGE_COUNT] = {};
 };
+
+extern "C" int flush_held(xb_ctx *ctx);      // launches a held-back asynchronous basecall (defined with it below)
 
 namespace {
 
@@ -542,7 +565,8 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
 }
 
 // scores_out: (T, n, ldc) with ldc given; expand selects the blank-column layout
-int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *scores_out, int ldc)
+int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *scores_out, int ldc,
+                const float *d_signal2 = nullptr, int split = 0)
 {
     const xb_config &c = ctx->cfg;
     const int F = c.features, T = ctx->T;
@@ -551,7 +575,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
     {
         StageScope sc(ctx, XB_STAGE_CONV, 2);
         xb::ConvFrontParams cf{};
-        cf.signal = d_signal; cf.N = n; cf.L = c.chunk_len; cf.T = T; cf.winlen = c.winlen; cf.stride = c.stride;
+        cf.signal = d_signal; cf.signal2 = d_signal2; cf.split = d_signal2 ? split : n; cf.N = n; cf.L = c.chunk_len; cf.T = T; cf.winlen = c.winlen; cf.stride = c.stride;
         cf.kp = ctx->kp; cf.w1 = ctx->w1; cf.b1 = ctx->b1; cf.w2 = ctx->w2; cf.b2 = ctx->b2;
         cf.a_hi = ctx->im_hi; cf.a_lo = ctx->im_lo; cf.q8 = nsplit == 2;
         XB_HIP(ctx, xb::launch_conv_front(cf, ctx->stream));
@@ -626,6 +650,7 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
 // third stream (they share the decode workspaces and the score buffers)
 int join_async_decode(xb_ctx *ctx)
 {
+    if (int rc = flush_held(ctx)) return rc;
     for (int p = 0; p < 2; ++p)
         if (ctx->dec_pending[p]) {
             XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[p], 0));
@@ -729,9 +754,13 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
         if (const char *e = getenv("XB_SLAB_STEPS")) ctx->slab_steps = atoi(e) >= 8 ? atoi(e) : 0;
         if (const char *e = getenv("XB_LSTM_SIGNAL")) ctx->lstm_signal = atoi(e) < 0 || atoi(e) > 2 ? 2 : atoi(e);
+        if (const char *e = getenv("XB_FUSE")) ctx->fuse = atoi(e) != 0;
     }
 
-    const size_t N = cfg->max_batch, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
+    // co-scheduling two calls needs room for both: only where the pair fits one launch of two groups per workgroup
+    if (!(ctx->fuse && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= 512)) ctx->fuse = 0;
+    ctx->cap = ctx->fuse ? 2 * cfg->max_batch : cfg->max_batch;
+    const size_t N = (size_t)ctx->cap, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
     const size_t Cb = (size_t)S * (cfg->n_base + 1);
     const size_t Cmax = Cb > (size_t)ctx->ld_nb ? Cb : (size_t)ctx->ld_nb;
     int rc = XB_OK;
@@ -757,6 +786,10 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);
+    if (ctx->fuse) {
+        rc = rc ? rc : dev_alloc(ctx, &ctx->fseq, N * T);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->flen, N);
+    }
     rc = rc ? rc : dev_alloc(ctx, &ctx->sync, (size_t)64 * 32 + 32 + 64);      // group slots, error word, slab arrival counters
     if (rc) {
         g_create_error = ctx->err;
@@ -793,6 +826,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
 XB_API void xb_ctx_destroy(xb_ctx *ctx)
 {
     if (!ctx) return;
+    ctx->holding = false;       // a call nobody waited for
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -929,7 +963,9 @@ XB_API int xb_synchronize(xb_ctx *ctx)
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = sync_all(ctx);
+    int rc = flush_held(ctx);
+    if (rc) return rc;
+    rc = sync_all(ctx);
     if (rc) return rc;
     return check_device_error(ctx);
 }
@@ -937,7 +973,19 @@ XB_API int xb_synchronize(xb_ctx *ctx)
 XB_API void *xb_result_stream(xb_ctx *ctx)
 {
     if (!ctx) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    (void)flush_held(ctx);        // a failure is recorded (pipeline_failed, xb_last_error) and reported by the next call
     return ctx->result_stream ? ctx->result_stream : ctx->stream;
+}
+
+// xb_comm: run fn(arg) right behind the held-back call that will write d_seq, instead of now (returns 1), or report that no
+// such call is held (0: the caller proceeds at once).  Not part of the public header.
+extern "C" __attribute__((visibility("default"))) int xb_internal_defer_after(xb_ctx *ctx, const void *d_seq, void (*fn)(void *), void *arg)
+{
+    if (!ctx || !ctx->holding || ctx->held.seq != d_seq || ctx->held.after) return 0;
+    ctx->held.after = fn;
+    ctx->held.after_arg = arg;
+    return 1;
 }
 
 XB_API int xb_stream_wait_event(xb_ctx *ctx, void *hip_event)
@@ -1281,36 +1329,118 @@ XB_API int xb_basecall_chunks_beam(xb_ctx *ctx, const float *signal, int n, cons
     return beam_results_to_host(ctx, ctx->T, n, sequence, qstring, moves, score);
 }
 
+// what follows a call's decode on its result stream: the host pipeline's D2H copies and done event, a deferred gather
+static int call_post_actions(xb_ctx *ctx, const xb_ctx::Call &c, hipStream_t rs)
+{
+    if (c.slot >= 0) {
+        xb_ctx::Slot &sl = ctx->slots[c.slot];
+        XB_HIP(ctx, hipMemcpyAsync(sl.h_seq, sl.d_seq, (size_t)c.n * ctx->T, hipMemcpyDeviceToHost, rs));
+        XB_HIP(ctx, hipMemcpyAsync(sl.h_len, sl.d_len, sizeof(int32_t) * (size_t)c.n, hipMemcpyDeviceToHost, rs));
+        // the error word as THIS batch left it (stream order: behind its recurrences and its decode), not as whatever batch
+        // happens to be running when the slot is collected finds it
+        XB_HIP(ctx, hipMemcpyAsync(sl.h_err, ctx->error, sizeof(unsigned), hipMemcpyDeviceToHost, rs));
+        XB_HIP(ctx, hipEventRecord(sl.done, rs));
+    }
+    if (c.after) c.after(c.after_arg);
+    return XB_OK;
+}
+
+// The asynchronous basecall of one call, or of two calls as one batch (chunks [0, a.n) = a, [a.n, a.n + b->n) = b).
+static int launch_calls(xb_ctx *ctx, const xb_ctx::Call &a, const xb_ctx::Call *b)
+{
+    const int n = a.n + (b ? b->n : 0);
+    int8_t *d_seq = b ? ctx->fseq : a.seq;
+    int32_t *d_len = b ? ctx->flen : a.len;
+    const float *sig2 = b ? b->signal : nullptr;
+    int rc;
+    hipStream_t rs;
+    if (!ctx->overlap || !ctx->stream3 || !ctx->scores2) {
+        rs = ctx->result_stream = ctx->stream;
+        rc = run_encoder(ctx, a.signal, n, 0, ctx->scores, ctx->ld_nb, sig2, a.n);
+        if (rc) return rc;
+        rc = run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, a.alphabet, nullptr, d_seq, d_len);
+        if (rc) return rc;
+    } else {
+        // asynchronous decode: the encoder of this batch writes score buffer p while the decode of the previous batch may
+        // still be reading buffer p ^ 1 on the third stream; the decode that used buffer p two calls ago must be done first
+        const int pb = (int)(ctx->batch_idx++ & 1u);
+        float *sc = pb ? ctx->scores2 : ctx->scores;
+        rs = ctx->result_stream = ctx->stream3;
+        if (ctx->dec_pending[pb]) XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[pb], 0));
+        rc = run_encoder(ctx, a.signal, n, 0, sc, ctx->ld_nb, sig2, a.n);
+        if (rc) return rc;
+        hipEvent_t enc;
+        if ((rc = next_dep(ctx, &enc))) return rc;
+        XB_HIP(ctx, hipEventRecord(enc, ctx->stream));
+        XB_HIP(ctx, hipStreamWaitEvent(ctx->stream3, enc, 0));
+        rc = run_decode(ctx, sc, ctx->T, n, 0, ctx->ld_nb, a.alphabet, nullptr, d_seq, d_len, ctx->stream3);
+        if (rc) return rc;
+    }
+    if (b) {        // the pair's rows back to where each caller wants them
+        const size_t T = (size_t)ctx->T;
+        XB_HIP(ctx, hipMemcpyAsync(a.seq, ctx->fseq, (size_t)a.n * T, hipMemcpyDeviceToDevice, rs));
+        XB_HIP(ctx, hipMemcpyAsync(b->seq, ctx->fseq + (size_t)a.n * T, (size_t)b->n * T, hipMemcpyDeviceToDevice, rs));
+        if (a.len) XB_HIP(ctx, hipMemcpyAsync(a.len, ctx->flen, sizeof(int32_t) * (size_t)a.n, hipMemcpyDeviceToDevice, rs));
+        if (b->len) XB_HIP(ctx, hipMemcpyAsync(b->len, ctx->flen + a.n, sizeof(int32_t) * (size_t)b->n, hipMemcpyDeviceToDevice, rs));
+    }
+    if (rs == ctx->stream3) {
+        const int pb = (int)((ctx->batch_idx - 1) & 1u);
+        XB_HIP(ctx, hipEventRecord(ctx->dec_done[pb], ctx->stream3));
+        ctx->dec_pending[pb] = true;
+    }
+    if ((rc = call_post_actions(ctx, a, rs))) return rc;
+    if (b && (rc = call_post_actions(ctx, *b, rs))) return rc;
+    return XB_OK;
+}
+
+// launch a held-back call on its own (every entry point that is not the asynchronous basecall comes through here first)
+int flush_held(xb_ctx *ctx)
+{
+    if (!ctx->holding || ctx->flushing) return XB_OK;
+    ctx->flushing = true;
+    const xb_ctx::Call h = ctx->held;
+    ctx->holding = false;
+    const int rc = launch_calls(ctx, h, nullptr);
+    ctx->flushing = false;
+    if (rc) ctx->pipeline_failed = true;        // the call itself had already returned XB_OK
+    return rc;
+}
+
+static int enqueue_call(xb_ctx *ctx, const xb_ctx::Call &c)
+{
+    if (ctx->holding) {
+        const xb_ctx::Call h = ctx->held;
+        ctx->holding = false;
+        const bool pair = ctx->fuse && h.n + c.n <= ctx->cap && strcmp(h.alphabet, c.alphabet) == 0 && h.seq != c.seq;
+        if (pair) {
+            const int rc = launch_calls(ctx, h, &c);
+            if (rc) ctx->pipeline_failed = true;
+            return rc;
+        }
+        const int rc = launch_calls(ctx, h, nullptr);
+        if (rc) { ctx->pipeline_failed = true; return rc; }
+    }
+    if (ctx->fuse && 2 * c.n <= ctx->cap) {
+        ctx->held = c;
+        ctx->holding = true;
+        return XB_OK;
+    }
+    return launch_calls(ctx, c, nullptr);
+}
+
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet, int8_t *d_seq,
                                   int32_t *d_seq_len)
 {
     int rc = check_ready(ctx, n);
     if (rc) return rc;
     if (!d_signal || !d_seq || !alphabet) return fail(ctx, XB_ERR_INVALID, "null argument");
+    if ((int)strlen(alphabet) < ctx->cfg.n_base + 1 || strlen(alphabet) >= sizeof(xb_ctx::Call{}.alphabet))
+        return fail(ctx, XB_ERR_INVALID, "alphabet needs %d symbols", ctx->cfg.n_base + 1);
     XB_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->overlap || !ctx->stream3 || !ctx->scores2) {
-        ctx->result_stream = ctx->stream;
-        rc = run_encoder(ctx, d_signal, n, 0, ctx->scores, ctx->ld_nb);
-        if (rc) return rc;
-        return run_decode(ctx, ctx->scores, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len);
-    }
-    // asynchronous decode: the encoder of this batch writes score buffer p while the decode of the previous batch may
-    // still be reading buffer p ^ 1 on the third stream; the decode that used buffer p two calls ago must be done first
-    const int pb = (int)(ctx->batch_idx++ & 1u);
-    float *sc = pb ? ctx->scores2 : ctx->scores;
-    ctx->result_stream = ctx->stream3;
-    if (ctx->dec_pending[pb]) XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dec_done[pb], 0));
-    rc = run_encoder(ctx, d_signal, n, 0, sc, ctx->ld_nb);
-    if (rc) return rc;
-    hipEvent_t enc;
-    if ((rc = next_dep(ctx, &enc))) return rc;
-    XB_HIP(ctx, hipEventRecord(enc, ctx->stream));
-    XB_HIP(ctx, hipStreamWaitEvent(ctx->stream3, enc, 0));
-    rc = run_decode(ctx, sc, ctx->T, n, 0, ctx->ld_nb, alphabet, nullptr, d_seq, d_seq_len, ctx->stream3);
-    if (rc) return rc;
-    XB_HIP(ctx, hipEventRecord(ctx->dec_done[pb], ctx->stream3));
-    ctx->dec_pending[pb] = true;
-    return XB_OK;
+    xb_ctx::Call c;
+    c.signal = d_signal; c.n = n; c.seq = d_seq; c.len = d_seq_len;
+    strcpy(c.alphabet, alphabet);
+    return enqueue_call(ctx, c);
 }
 
 XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const char *alphabet, int8_t *seq,
@@ -1364,15 +1494,15 @@ XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, c
     XB_HIP(ctx, hipMemcpyAsync(sl.d_signal, sl.h_signal, bytes, hipMemcpyHostToDevice, ctx->stream_copy));
     XB_HIP(ctx, hipEventRecord(sl.h2d, ctx->stream_copy));
     XB_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.h2d, 0));
-    rc = xb_basecall_chunks_dev(ctx, sl.d_signal, n, alphabet, sl.d_seq, sl.d_len);
+    if ((int)strlen(alphabet) < ctx->cfg.n_base + 1 || strlen(alphabet) >= sizeof(xb_ctx::Call{}.alphabet))
+        return fail(ctx, XB_ERR_INVALID, "alphabet needs %d symbols", ctx->cfg.n_base + 1);
+    // the D2H copies of the results, the error-word snapshot and the slot's done event follow the launch of this call
+    // (call_post_actions) -- which may be held back until the next submit so that the two batches share one pass
+    xb_ctx::Call c;
+    c.signal = sl.d_signal; c.n = n; c.seq = sl.d_seq; c.len = sl.d_len; c.slot = slot;
+    strcpy(c.alphabet, alphabet);
+    rc = enqueue_call(ctx, c);
     if (rc) return rc;
-    hipStream_t rs = ctx->result_stream ? ctx->result_stream : ctx->stream;
-    XB_HIP(ctx, hipMemcpyAsync(sl.h_seq, sl.d_seq, (size_t)n * ctx->T, hipMemcpyDeviceToHost, rs));
-    XB_HIP(ctx, hipMemcpyAsync(sl.h_len, sl.d_len, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, rs));
-    // the error word as THIS batch left it (stream order: behind its recurrences and its decode), not as whatever batch
-    // happens to be running when the slot is collected finds it
-    XB_HIP(ctx, hipMemcpyAsync(sl.h_err, ctx->error, sizeof(unsigned), hipMemcpyDeviceToHost, rs));
-    XB_HIP(ctx, hipEventRecord(sl.done, rs));
     sl.n = n;
     sl.busy = true;
     return XB_OK;
@@ -1385,6 +1515,7 @@ XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_le
     xb_ctx::Slot &sl = ctx->slots[slot];
     if (!sl.busy) return fail(ctx, XB_ERR_STATE, "slot %d has nothing in flight", slot);
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->holding && ctx->held.slot == slot) (void)flush_held(ctx);      // a failure shows as pipeline_failed below
     XB_HIP(ctx, hipEventSynchronize(sl.done));
     sl.busy = false;
     memcpy(seq, sl.h_seq, (size_t)sl.n * ctx->T);
@@ -1415,6 +1546,7 @@ XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t lau
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_held(ctx)) return rc;
     if (int rc = sync_all(ctx)) return rc;
     collect_events(ctx);
     for (int i = 0; i < XB_STAGE_COUNT; ++i) {
@@ -1427,6 +1559,7 @@ XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t lau
 XB_API int xb_reset_stage_times(xb_ctx *ctx)
 {
     if (!ctx) return XB_ERR_INVALID;
+    if (int rc = flush_held(ctx)) return rc;
     if (int rc = sync_all(ctx)) return rc;
     collect_events(ctx);
     for (int i = 0; i < XB_STAGE_COUNT; ++i) { ctx->stage_ms[i] = 0.f; ctx->stage_launches[i] = 0; }

@@ -72,7 +72,9 @@ struct xb_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr, done[2] = {};       // producer -> gather; gather -> producer (the last two gathers)
-    unsigned issued = 0;
+    unsigned issued = 0;          // gathers enqueued on the stream so far
+    unsigned queued = 0;          // gathers asked for so far (a gather can wait for a held-back basecall: xb_gather_called)
+    int deferred_rc = 0;          // failure of a deferred gather, reported by the next call
     std::string err;
 };
 
@@ -143,11 +145,46 @@ XB_API void xb_comm_destroy(xb_comm *c)
 XB_API int xb_comm_rank(const xb_comm *c) { return c ? c->rank : -1; }
 XB_API int xb_comm_world(const xb_comm *c) { return c ? c->world : 0; }
 
+extern "C" int xb_internal_defer_after(xb_ctx *ctx, const void *d_seq, void (*fn)(void *), void *arg);
+
+namespace {
+struct GatherArgs {
+    xb_comm *c; xb_ctx *ctx; const int8_t *d_seq; const int32_t *d_len; int n, T; int8_t *all_seq; int32_t *all_len;
+};
+int gather_now(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_seq_len, int n, int T, int8_t *d_all_seq,
+               int32_t *d_all_len);
+// the gather of a call that was held back when xb_gather_called came: runs right behind that call's launch
+void gather_later(void *p)
+{
+    GatherArgs *g = static_cast<GatherArgs *>(p);
+    const int rc = gather_now(g->c, g->ctx, g->d_seq, g->d_len, g->n, g->T, g->all_seq, g->all_len);
+    if (rc != XB_OK) g->c->deferred_rc = rc;        // reported by the next xb_gather_called / xb_comm_synchronize
+    delete g;
+}
+}  // namespace
+
 XB_API int xb_gather_called(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_seq_len, int n, int T,
                             int8_t *d_all_seq, int32_t *d_all_len)
 {
     if (!c) return XB_ERR_INVALID;
     if (!d_seq || !d_seq_len || !d_all_seq || !d_all_len || n < 1 || T < 1) return cfail(c, XB_ERR_INVALID, "bad argument");
+    if (c->deferred_rc != XB_OK) { const int rc = c->deferred_rc; c->deferred_rc = XB_OK; return rc; }
+    if (ctx) {
+        // the basecall that writes d_seq may be held back to share a pass with the next one (xb_basecall_chunks_dev): the gather
+        // is then enqueued right behind its launch, in the order of the xb_gather_called calls
+        GatherArgs *g = new GatherArgs{c, ctx, d_seq, d_seq_len, n, T, d_all_seq, d_all_len};
+        if (xb_internal_defer_after(ctx, d_seq, &gather_later, g)) { c->queued += 1; return XB_OK; }
+        delete g;
+        if (c->queued != c->issued) (void)xb_result_stream(ctx);     // an older gather is still waiting for its basecall: launch it first
+    }
+    c->queued += 1;
+    return gather_now(c, ctx, d_seq, d_seq_len, n, T, d_all_seq, d_all_len);
+}
+
+namespace {
+int gather_now(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_seq_len, int n, int T, int8_t *d_all_seq,
+               int32_t *d_all_len)
+{
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
     // order the gather behind the stream that produces (d_seq, d_seq_len); without a context the caller has synchronised
     if (ctx) {
@@ -165,14 +202,18 @@ XB_API int xb_gather_called(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const 
     c->issued += 1;
     return XB_OK;
 }
+}  // namespace
 
 XB_API int xb_comm_fence(xb_comm *c, xb_ctx *ctx, int lag)
 {
     if (!c || !ctx || lag < 0 || lag > 1) return XB_ERR_INVALID;
-    if (c->issued <= (unsigned)lag) return XB_OK;           // nothing that old has been issued
+    if (c->queued <= (unsigned)lag) return XB_OK;           // nothing that old has been asked for
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
     // the gathers run in order on one stream: waiting for gather (latest - lag) covers every earlier one
-    hipEvent_t ev = c->done[(c->issued - 1 - (unsigned)lag) & 1];
+    const unsigned target = c->queued - 1 - (unsigned)lag;
+    if (target >= c->issued) (void)xb_result_stream(ctx);  // it still waits for a held-back basecall: launch that now
+    if (target >= c->issued || c->issued - target > 2) return cfail(c, XB_ERR_STATE, "fence: that gather's event is gone");
+    hipEvent_t ev = c->done[target & 1];
     return xb_stream_wait_event(ctx, ev) == XB_OK ? XB_OK : cfail(c, XB_ERR_HIP, "stream wait failed");
 }
 
@@ -181,6 +222,7 @@ XB_API int xb_comm_synchronize(xb_comm *c)
     if (!c) return XB_ERR_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
     if (hipStreamSynchronize(c->stream) != hipSuccess) return cfail(c, XB_ERR_HIP, "gather stream failed");
+    if (c->deferred_rc != XB_OK) { const int rc = c->deferred_rc; c->deferred_rc = XB_OK; return rc; }
     return XB_OK;
 }
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_front_kernel(xb::ConvFrontParams p)
     if (tid < 16) b2s[tid] = p.b2[tid];
     if (tid < 20) w1s[tid] = p.w1[tid];
     if (tid < 4) b1s[tid] = p.b1[tid];
-    const float *x = p.signal + (size_t)n * L;
+    const float *x = (p.signal2 && n >= p.split) ? p.signal2 + (size_t)(n - p.split) * L : p.signal + (size_t)n * L;
     for (int i = tid; i < nq + 8; i += 256) {
         const int pos = q0 - 4 + i;
         sig[i] = (pos >= 0 && pos < L) ? x[pos] : 0.0f;

@@ -83,7 +83,9 @@ hipError_t launch_beam_search(const BeamParams &p, hipStream_t stream);
 // conv1(1->4,k5,p2)+SiLU, conv2(4->16,k5,p2)+SiLU, then the im2col rows of conv3
 // (row (t*N+n), col c*winlen+k = a2[c][t*stride - winlen/2 + k]) as split fp16, K padded to kp.
 struct ConvFrontParams {
-    const float *signal;   // (N, L)
+    const float *signal;   // (N, L); with signal2 set: chunks [0, split) come from signal, chunks [split, N) from signal2
+    const float *signal2;  // (N - split, L) or nullptr: the second of two batches that share one pass through the encoder
+    int split;
     int N, L, T, winlen, stride, kp;
     const float *w1, *b1;  // (4,1,5), (4)
     const float *w2, *b2;  // (16,4,5), (16)

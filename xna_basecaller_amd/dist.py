@@ -253,6 +253,7 @@ class RcclGather:
         return prev
 
     def flush(self):
+        self.ctx.result_stream()            # a basecall held back for co-scheduling is launched now, its gather behind it
         self.comm.synchronize()
         prev, self._prev = self._prev, None
         return prev
