@@ -56,9 +56,11 @@ def cpu_baseline(sd, features, n_base, L, chunks, alphabet, repeats=3):
                       % (chunks, L, n_base, repeats, "/".join("%.1f" % t for t in times))}
 
 
-def measured_traffic(kernel_prefix, nb, batch, chunksize, precision):
+def measured_traffic(kernel_prefix, nb, batch, chunksize, precision, launches_per_step):
     """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE
-    collected in separate rocprofv3 runs, gfx950 correction applied) -- only when they were taken on this configuration."""
+    collected in separate rocprofv3 runs, gfx950 correction applied) -- only when they were taken on this configuration.
+    The passes count bytes per bench step; they are divided by THIS run's launches per step (counter collection runs the
+    recurrence as slab launches, the timed run as one launch per layer: the bytes are the same, the launch count is not)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
         try:
@@ -70,6 +72,8 @@ def measured_traffic(kernel_prefix, nb, batch, chunksize, precision):
             continue
         for name, k in d.get("kernels", {}).items():
             if name.startswith(kernel_prefix):
+                if "steps" in d and launches_per_step > 0:
+                    return k.get("hbm_bytes_all_launches") / d["steps"] / launches_per_step
                 return k.get("hbm_bytes_per_launch")
     return None
 
@@ -223,7 +227,7 @@ def main():
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
-                "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision),
+                "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K)),
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches, "launches_per_step": rec_launches / K,
                 "note": "algorithmic fp32-equivalent FLOPs; f16x3 issues 3 fp16 MFMA products per FLOP pair, "
                         "f16f8 one fp16 product + one block-scaled FP8 MFMA (2x rate) for both corrections"}
@@ -235,7 +239,7 @@ def main():
     dec_gbs = a_dec / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
     roofline_decode = {"kernel": "crf_decode_kernel", "bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS,
-                       "traffic": measured_traffic("crf_decode_kernel", nb, N, L, args.precision), "algorithmic_bytes": a_dec,
+                       "traffic": measured_traffic("crf_decode_kernel", nb, N, L, args.precision, dec_launches / float(K)), "algorithmic_bytes": a_dec,
                        "avg_launch_ms": 1e3 * dec_avg_s, "launches": dec_launches,
                        "decode_only_samples_per_s": N * L / dec_avg_s if dec_avg_s > 0 else 0.0}
 

@@ -25,7 +25,14 @@
  *     torch tensor data_ptr()), enqueue on the ctx's streams and return without waiting.  The ONLY completion
  *     point is xb_synchronize (it joins all of the ctx's streams): call it before reading results or reusing /
  *     freeing the buffers passed in.  Consecutive xb_basecall_chunks_dev calls pipeline (decode of batch k overlaps
- *     the encoder of batch k+1): give each in-flight batch its own d_seq / d_seq_len.
+ *     the encoder of batch k+1): give each in-flight batch its own d_seq / d_seq_len -- and its own d_signal that
+ *     stays untouched until xb_synchronize (or until work ordered behind xb_result_stream has run).
+ *   - two batches in flight are CO-SCHEDULED (contexts of at most 512 chunks; XB_FUSE=0 switches it off): an
+ *     xb_basecall_chunks_dev / xb_submit_chunks that finds nothing held back is itself held back (nothing is enqueued yet)
+ *     until the next such call arrives; the two batches then go through the encoder and the decode as one -- the recurrence
+ *     serves two chunk groups per workgroup and hides one group's hand-off behind the other's arithmetic -- and each
+ *     call's results land in its own buffers.  A held-back call is launched on its own by every other entry point,
+ *     by xb_synchronize, xb_result_stream and xb_collect_chunks of its slot; results are the same bytes either way.
  *   - layouts are the reference's: signal (N, L) fp32 [= (N,1,L)], scores (T, N, C) fp32
  *     time-major, labels / seq (N, T) int8.
  */

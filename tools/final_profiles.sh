@@ -2,23 +2,28 @@
 #   bench lines of the default build (configs[2], configs[1], the per-GPU workloads of configs[3] / [4], the peaky model),
 #   the recurrence's cycle stamps (diagnostic library), rocprofv3 kernel-trace stats of the bench command, and the PMC passes
 #   (FETCH_SIZE / WRITE_SIZE for roofline.traffic; MFMA-busy / clock / L2 for the GEMM and the recurrence).
+# One call may run 1200 s at most: PART=bench (the bench lines) and PART=prof (stamps, kernel trace, PMC passes) split it.
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
-if [ -z "$SKIP_BENCH" ]; then
+if [ "$PART" != "prof" ]; then
 timeout -k 10 300 python bench.py --steps 6 --warmup 2 > $O/bench_nb6.json 2> $O/bench.err
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 --nbase 5 --cpu-chunks 0 > $O/bench_nb5.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 6 --warmup 2 --nbase 5 --cpu-chunks 0 > $O/bench_nb5.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 1024 --cpu-chunks 0 > $O/bench_n1024.json 2>> $O/bench.err
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --batch 2048 --cpu-chunks 0 > $O/bench_n2048.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 2048 --cpu-chunks 0 > $O/bench_n2048.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --weights peaky --cpu-chunks 0 > $O/bench_nb6_peaky.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 448 --cpu-chunks 0 > $O/bench_n448.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --batch 98 --cpu-chunks 0 > $O/bench_n98.json 2>> $O/bench.err
 XB_OVERLAP=0 timeout -k 10 300 python bench.py --steps 4 --warmup 2 --cpu-chunks 0 > $O/bench_nb6_serial.json 2>> $O/bench.err
+XB_FUSE=0 timeout -k 10 300 python bench.py --steps 6 --warmup 2 --cpu-chunks 0 > $O/bench_nb6_nofuse.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-chunks 0 > $O/bench_nb6_steps20.json 2>> $O/bench.err
 fi
+if [ "$PART" != "bench" ]; then
 (export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1
 cd $R
 bash tools/pmc_gemm.sh r03/pmc512 > $O/pmc512.log 2>&1
 XB_OVERLAP=0 bash tools/pmc_gemm.sh r03/pmc512_serial > $O/pmc512_serial.log 2>&1
+fi
 echo done > $O/done.txt

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--precision", default="f16f8")
     ap.add_argument("--note", default="")
+    ap.add_argument("--steps", type=int, default=2, help="bench steps the PMC passes covered (tools/pmc_gemm.sh: 2)")
     args = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(args.pmcdir + "/p*/**/*counter_collection.csv", recursive=True):
@@ -38,10 +39,11 @@ def main():
         kernels[name] = {"launches": n, "fetch_size_kib": fetch, "write_size_kib": write,
                          "hbm_bytes_per_launch": per, "hbm_bytes_all_launches": per * n}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_gemm.sh with PASSES=2) over "
-                     "`bench.py --steps 1 --warmup 0 --cpu-chunks 0`; MI355X. Per-launch means. " + args.note,
+                     "`bench.py --steps 2 --warmup 0 --cpu-chunks 0`; MI355X. Per-launch means. " + args.note,
            "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for 16-B-per-lane "
                          "loads -> fetch bytes = 2 x FETCH_SIZE KiB x 1024; WRITE_SIZE is exact for 16-B-per-lane stores. "
                          "Infinity-Cache hits are counted.",
+           "steps": args.steps,
            "config": {"n_base": args.nbase, "batch_per_gpu": args.batch, "chunksize": args.chunksize,
                       "precision": args.precision},
            "kernels": kernels}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over one bench step (each pass = its own rocprofv3 run; counters only, no traces).
+# PMC passes over two bench steps (one co-scheduled pair of calls in the default schedule) (each pass = its own rocprofv3 run; counters only, no traces).
 # PASSES=2 limits the run to the first two sets (FETCH_SIZE, WRITE_SIZE: they do not fit one pass together).
 # usage: tools/pmc_gemm.sh OUTDIR   (run on the GPU box from the repo root)
 set -e
@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
   if [ -n "$PASSES" ] && [ $i -gt $PASSES ]; then break; fi
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-chunks 0 $BENCH_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
+  timeout -k 10 100 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --cpu-chunks 0 $BENCH_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
 done
 python3 - <<PY
 import csv, glob, collections, re

@@ -755,6 +755,12 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         if (const char *e = getenv("XB_SLAB_STEPS")) ctx->slab_steps = atoi(e) >= 8 ? atoi(e) : 0;
         if (const char *e = getenv("XB_LSTM_SIGNAL")) ctx->lstm_signal = atoi(e) < 0 || atoi(e) > 2 ? 2 : atoi(e);
         if (const char *e = getenv("XB_FUSE")) ctx->fuse = atoi(e) != 0;
+        // rocprofv3 counter collection (--pmc) runs one kernel at a time; hipStreamWaitValue32 is a spinning kernel
+        // (__amd_rocclr_streamOpsWait) there, which would wait for a flag the serialised recurrence can never raise: slab launches
+        {
+            const char *cc = getenv("ROCPROF_COUNTER_COLLECTION"), *cn = getenv("ROCPROF_COUNTERS");
+            if ((cc && atoi(cc) != 0) || (cn && *cn)) ctx->lstm_signal = 0;
+        }
     }
 
     // co-scheduling two calls needs room for both: only where the pair fits one launch of two groups per workgroup
