@@ -126,6 +126,7 @@ def main():
     ctx = _lib.Context(local, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=prec, lstm_mode=args.lstm_mode)
     sd = peaky_weights(F, nb) if args.weights == "peaky" else seeded_weights(F, nb)
     ctx.load_state_dict(sd)
+    ctx.reserve_pairing()           # two calls in flight are co-scheduled: their workspaces now, not inside the timed region
     T = ctx.T
 
     # synthetic signal ~ N(0,1) generated on the device (Philox counter RNG, seeded by (25, rank)): resident in HBM

@@ -204,6 +204,11 @@ XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const cha
                               int8_t *seq, int32_t *seq_len);
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet,
                                   int8_t *d_seq, int32_t *d_seq_len);
+/* Room for two co-scheduled calls (see the header comment): a context allocates workspaces for max_batch chunks and replaces
+ * them by twice that the first time two calls are paired -- which waits for everything in flight and takes a second or two.
+ * A caller that will keep two batches in flight can have that done up front (bench.py does, outside its timed region).
+ * XB_OK also when the context does not pair calls (XB_FUSE=0, max_batch > 512, serial schedule). */
+XB_API int xb_reserve_pairing(xb_ctx *ctx);
 
 /*
  * The same operator for a host pipeline that keeps the device busy (crf/basecall.py:96-119: the reference overlaps its

@@ -24,7 +24,7 @@ EXPORTS = [
     "xb_submit_chunks", "xb_collect_chunks", "xb_ctc_logz", "xb_ctc_alignments",
     "xb_comm_unique_id", "xb_comm_create", "xb_comm_destroy", "xb_comm_rank", "xb_comm_world", "xb_comm_last_error",
     "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event", "xb_align_accuracy",
-    "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam",
+    "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam", "xb_reserve_pairing",
 ]
 XB_COMM_ID_BYTES = 128
 
@@ -79,6 +79,7 @@ def load():
     lib.xb_basecall_chunks.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
+    lib.xb_reserve_pairing.argtypes = [vp]
     lib.xb_comm_unique_id.argtypes = [C.c_char_p]
     lib.xb_comm_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.c_char_p]
     lib.xb_comm_destroy.argtypes = [vp]
@@ -344,6 +345,10 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.xb_synchronize(self.h))
+
+    def reserve_pairing(self):
+        """Allocate the workspaces for two co-scheduled calls now instead of at the first pairing."""
+        self._check(self.lib.xb_reserve_pairing(self.h))
 
     def result_stream(self):
         """hipStream_t (int) producing the outputs of the most recent *_dev call (xb_result_stream)."""

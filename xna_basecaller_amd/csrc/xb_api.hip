@@ -70,6 +70,8 @@ struct xb_ctx {
     bool weights_ready = false;
     std::map<std::string, std::vector<float>> host_w;
     std::vector<DevBuf> bufs;
+    std::vector<DevBuf> wsbufs;                // the batch-sized workspaces (alloc_workspaces)
+    bool alloc_ws = false;
 
     // weights on device
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *b3 = nullptr;
@@ -177,9 +179,53 @@ int dev_alloc(xb_ctx *ctx, Tp **out, size_t count)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess)
         return fail(ctx, XB_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
-    ctx->bufs.push_back({p, bytes});
+    (ctx->alloc_ws ? ctx->wsbufs : ctx->bufs).push_back({p, bytes});
     *out = reinterpret_cast<Tp *>(p);
     return XB_OK;
+}
+
+// The workspaces whose size follows the number of chunks in a pass.  A context starts with room for max_batch chunks; the
+// first time two calls are co-scheduled (or on xb_reserve_pairing) they are replaced by twice that.
+int alloc_workspaces(xb_ctx *ctx, int cap)
+{
+    for (auto &b : ctx->wsbufs) (void)hipFree(b.p);
+    ctx->wsbufs.clear();
+    ctx->cap = 0;
+    const xb_config *cfg = &ctx->cfg;
+    const int S = ctx->S;
+    const size_t N = (size_t)cap, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
+    const size_t Cb = (size_t)S * (cfg->n_base + 1);
+    const size_t Cmax = Cb > (size_t)ctx->ld_nb ? Cb : (size_t)ctx->ld_nb;
+    ctx->alloc_ws = true;
+    int rc = XB_OK;
+    rc = rc ? rc : dev_alloc(ctx, &ctx->d_signal, N * L);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->im_hi, T * N * ctx->kp);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->im_lo, T * N * ctx->kp);
+    for (int i = 0; i < 2 && !rc; ++i) {
+        rc = rc ? rc : dev_alloc(ctx, &ctx->x_hi[i], T * N * F);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->x_lo[i], T * N * F);
+    }
+    // + 64 rows: the recurrence's LDS-DMA of a ragged last group reads (and ignores) up to 63 rows past the last chunk
+    rc = rc ? rc : dev_alloc(ctx, &ctx->gin, (T * N + 64) * 4 * F);
+    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, (T * N + 64) * 4 * F);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
+    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->scores2, T * N * (size_t)ctx->ld_nb);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->logz, N);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->qbuf, T * N * ((Cb + 3) & ~(size_t)3));
+    rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
+    rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);
+    if (ctx->fuse) {         // results of a pair before they are split (two short calls can pair inside max_batch chunks)
+        rc = rc ? rc : dev_alloc(ctx, &ctx->fseq, N * T);
+        rc = rc ? rc : dev_alloc(ctx, &ctx->flen, N);
+    }
+    ctx->alloc_ws = false;
+    if (!rc) ctx->cap = cap;
+    return rc;
 }
 
 struct StageScope {
@@ -763,39 +809,11 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         }
     }
 
-    // co-scheduling two calls needs room for both: only where the pair fits one launch of two groups per workgroup
+    // co-scheduling two calls: only where the pair fits one launch of two groups per workgroup
     if (!(ctx->fuse && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= 512)) ctx->fuse = 0;
-    ctx->cap = ctx->fuse ? 2 * cfg->max_batch : cfg->max_batch;
-    const size_t N = (size_t)ctx->cap, T = ctx->T, F = cfg->features, L = cfg->chunk_len;
-    const size_t Cb = (size_t)S * (cfg->n_base + 1);
-    const size_t Cmax = Cb > (size_t)ctx->ld_nb ? Cb : (size_t)ctx->ld_nb;
-    int rc = XB_OK;
-    rc = rc ? rc : dev_alloc(ctx, &ctx->d_signal, N * L);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->im_hi, T * N * ctx->kp);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->im_lo, T * N * ctx->kp);
-    for (int i = 0; i < 2 && !rc; ++i) {
-        rc = rc ? rc : dev_alloc(ctx, &ctx->x_hi[i], T * N * F);
-        rc = rc ? rc : dev_alloc(ctx, &ctx->x_lo[i], T * N * F);
-    }
-    // + 64 rows: the recurrence's LDS-DMA of a ragged last group reads (and ignores) up to 63 rows past the last chunk
-    rc = rc ? rc : dev_alloc(ctx, &ctx->gin, (T * N + 64) * 4 * F);
-    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, (T * N + 64) * 4 * F);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
+    const size_t F = cfg->features;
+    int rc = alloc_workspaces(ctx, cfg->max_batch);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
-    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->scores2, T * N * (size_t)ctx->ld_nb);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->logz, N);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->qbuf, T * N * ((Cb + 3) & ~(size_t)3));
-    rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);
-    if (ctx->fuse) {
-        rc = rc ? rc : dev_alloc(ctx, &ctx->fseq, N * T);
-        rc = rc ? rc : dev_alloc(ctx, &ctx->flen, N);
-    }
     rc = rc ? rc : dev_alloc(ctx, &ctx->sync, (size_t)64 * 32 + 32 + 64);      // group slots, error word, slab arrival counters
     if (rc) {
         g_create_error = ctx->err;
@@ -850,6 +868,7 @@ XB_API void xb_ctx_destroy(xb_ctx *ctx)
     for (auto &e : ctx->deps) (void)hipEventDestroy(e);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto &b : ctx->bufs) (void)hipFree(b.p);
+    for (auto &b : ctx->wsbufs) (void)hipFree(b.p);
     for (void *w : ctx->wbufs) (void)hipFree(w);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1335,6 +1354,31 @@ XB_API int xb_basecall_chunks_beam(xb_ctx *ctx, const float *signal, int n, cons
     return beam_results_to_host(ctx, ctx->T, n, sequence, qstring, moves, score);
 }
 
+// room for two co-scheduled calls (once per context; everything in flight is waited for, no held call exists here)
+static int reserve_pairing(xb_ctx *ctx)
+{
+    if (!ctx->fuse) return XB_ERR_STATE;
+    if (ctx->cap >= 2 * ctx->cfg.max_batch) return XB_OK;
+    int rc = sync_all(ctx);
+    if (rc) return rc;
+    rc = alloc_workspaces(ctx, 2 * ctx->cfg.max_batch);
+    if (rc) {                                           // out of memory: back to one call per pass for good
+        ctx->fuse = 0;
+        const int rc2 = alloc_workspaces(ctx, ctx->cfg.max_batch);
+        return rc2 ? rc2 : rc;
+    }
+    return XB_OK;
+}
+
+XB_API int xb_reserve_pairing(xb_ctx *ctx)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_held(ctx)) return rc;
+    if (!ctx->fuse) return XB_OK;                       // nothing to reserve: every call runs on its own
+    return reserve_pairing(ctx);
+}
+
 // what follows a call's decode on its result stream: the host pipeline's D2H copies and done event, a deferred gather
 static int call_post_actions(xb_ctx *ctx, const xb_ctx::Call &c, hipStream_t rs)
 {
@@ -1417,7 +1461,8 @@ static int enqueue_call(xb_ctx *ctx, const xb_ctx::Call &c)
     if (ctx->holding) {
         const xb_ctx::Call h = ctx->held;
         ctx->holding = false;
-        const bool pair = ctx->fuse && h.n + c.n <= ctx->cap && strcmp(h.alphabet, c.alphabet) == 0 && h.seq != c.seq;
+        bool pair = ctx->fuse && h.n + c.n <= 2 * ctx->cfg.max_batch && strcmp(h.alphabet, c.alphabet) == 0 && h.seq != c.seq;
+        if (pair && h.n + c.n > ctx->cap && reserve_pairing(ctx) != XB_OK) pair = false;     // no room for both: one by one
         if (pair) {
             const int rc = launch_calls(ctx, h, &c);
             if (rc) ctx->pipeline_failed = true;
@@ -1426,7 +1471,7 @@ static int enqueue_call(xb_ctx *ctx, const xb_ctx::Call &c)
         const int rc = launch_calls(ctx, h, nullptr);
         if (rc) { ctx->pipeline_failed = true; return rc; }
     }
-    if (ctx->fuse && 2 * c.n <= ctx->cap) {
+    if (ctx->fuse) {
         ctx->held = c;
         ctx->holding = true;
         return XB_OK;
