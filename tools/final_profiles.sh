@@ -19,7 +19,7 @@ XB_FUSE=0 timeout -k 10 300 python bench.py --steps 6 --warmup 2 --cpu-chunks 0 
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --cpu-chunks 0 > $O/bench_nb6_steps20.json 2>> $O/bench.err
 fi
 if [ "$PART" != "bench" ]; then
-(export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1)
+(export XNA_LIBXNACALL=$R/xna_basecaller_amd/libxnacall_diag.so PREC=2 XB_OVERLAP=0; N=512 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_single.txt 2>&1; N=1024 timeout -k 10 200 python tools/lstm_stamps.py > $O/lstm_stamps_dual.txt 2>&1) || echo "stamps failed (stale diagnostic library? make -C xna_basecaller_amd/csrc diag)" >> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1
 cd $R

@@ -4,7 +4,7 @@
 # usage: tools/pmc_gemm.sh OUTDIR   (run on the GPU box from the repo root)
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc}
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT      # a fresh directory: the summaries take every csv they find
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/counters.txt 2>&1 || true
 i=0

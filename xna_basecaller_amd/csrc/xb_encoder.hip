@@ -1088,16 +1088,20 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     //      fetch of the next step starts with a fabric round trip; a plain store keeps it there, and a group's members
     //      normally share an XCD (blocks b, b + 8, .. under round-robin dispatch).  "Normally" is not a contract, so the
     //      members PROVE it per launch: each ORs the bit of the XCD it actually runs on (HW_REG_XCC_ID) into a word of its
-    //      group's sync slot; when a member's first wait for the group has completed, every member has posted its bit (the OR
+    //      group's sync slot; when a member's second wait for the group has completed, every member has posted its bit (the OR
     //      is older than the member's first arrival), and a mask with exactly one bit set switches this workgroup's later
     //      exchange stores to plain ones (the loads stay sc1 = L2-served).  Any other mask -- members on several XCDs, the
     //      placement test -- keeps the write-through form, which is correct anywhere.  One-group-per-workgroup kernel only.
     // (mask word and shift are recomputed from the kernel arguments where they are used: nothing extra stays live in the loop)
-    if (!DUAL && p.persistent && p.xcd_local && tid == 0) {
+    // (two groups per workgroup: both groups have the same member workgroups, each posts into both groups' words and decides
+    //  per group at that group's first wait; sFlag[2 + gi])
+    if (p.persistent && p.xcd_local && tid == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;        // HW_REG_XCC_ID[3:0]
-        __hip_atomic_fetch_or(cnt + 1 + ((p.slab >> 2) & 3), 1u << (8 * (p.slab & 3) + xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int gi = 0; gi < (second ? 2 : 1); ++gi)
+            __hip_atomic_fetch_or(p.sync + (size_t)(p.grp0 + grp + gi * gh) * 32 + 1 + ((p.slab >> 2) & 3), 1u << (8 * (p.slab & 3) + xcc),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) sFlag[2] = 0;
+    if (tid == 0) { sFlag[2] = 0; sFlag[3] = 0; }
 #ifdef XB_LSTM_STAMPS
     unsigned long long *sStamp = reinterpret_cast<unsigned long long *>(sFlag + 4);
     if (tid == 0) for (int i = 0; i < 10; ++i) sStamp[i] = 0;
@@ -1237,11 +1241,6 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                                 }
                             }
                             *sFlag = ok;
-                            if (!DUAL && p.xcd_local && s == p.s_begin + 1) {
-                                const unsigned m = (__hip_atomic_load(cnt + 1 + ((p.slab >> 2) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
-                                                    (8 * (p.slab & 3))) & 0xffu;
-                                sFlag[2] = (m != 0 && (m & (m - 1)) == 0) ? 1 : 0;      // all members on ONE XCD
-                            }
                         }
                         __syncthreads();
                         if (*sFlag == 0) {
@@ -1261,6 +1260,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 // (early: the drain wait and barrier that ended the previous group-step covered the first piece and this
                 //  group's gin tile, both older than the exchange stores drained there)
                 XB_STAMP(2);   // first piece landed
+                // the group's second hand-off is complete (blocking poll or, with two groups per workgroup, the look-ahead one):
+                // every member has arrived at least once, so every member's XCD bit is in the mask
+                if (p.xcd_local && s == p.s_begin + 2 && tid == 0) {
+                    const unsigned m = (__hip_atomic_load(cnt + 1 + ((p.slab >> 2) & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
+                                        (8 * (p.slab & 3))) & 0xffu;
+                    sFlag[2 + gi] = (m != 0 && (m & (m - 1)) == 0) ? 1 : 0;      // all members on ONE XCD
+                }
                 half8 w0 = wh[0];
                 if (PARK) {
                     int to = tid;
@@ -1543,7 +1549,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     store16_sc1(xb, vd);
                 } else {
                 half_t *xcur = xg + (size_t)(s & 1) * XPAR + (size_t)orow * F + mb * LG_UNITS + occ * 8;
-                if (!DUAL && __builtin_amdgcn_readfirstlane(sFlag[2]) != 0) {      // the group sits on one XCD (proven above)
+                if (__builtin_amdgcn_readfirstlane(sFlag[2 + gi]) != 0) {      // the group sits on one XCD (proven above)
                     store16_l2(xcur, vhi);
                     if (NSPLIT != 1) store16_l2(xcur + XPART, vlo);
                 } else {
