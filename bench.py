@@ -86,8 +86,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="chunks per GPU per step")
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--nbase", type=int, default=6, choices=[4, 5, 6])
