@@ -23,6 +23,7 @@ def run(N, sd, d_signal, env, steps=3):
     for k in env:
         os.environ.pop(k)
     ctx.load_state_dict(sd)
+    ctx.reserve_pairing()          # room for two co-scheduled calls now, not inside a timed loop
     T = ctx.T
     seqs = [torch.full((N, T), -1, dtype=torch.int8, device="cuda") for _ in range(steps)]
     lens = [torch.full((N,), -1, dtype=torch.int32, device="cuda") for _ in range(steps)]
