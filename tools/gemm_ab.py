@@ -27,7 +27,6 @@ def encode(gemm4, F, nb, L, N, prec, x, sd, lstm_mode=0):
     os.environ["XB_GEMM4"] = str(int(gemm4))
     ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=PREC[prec], lstm_mode=lstm_mode)
     ctx.load_state_dict(sd)
-    ctx.reserve_pairing()          # room for two co-scheduled calls now, not inside a timed loop
     out = ctx.encode(x)
     ctx.close()
     return out
