@@ -229,6 +229,8 @@ def main():
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
                 "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K)),
+                # what a launch has to move: its gin tiles in (fp32, 4F per chunk and step), the layer output out (hi + q8 image)
+                "algorithmic_bytes": 5.0 * K / max(rec_launches, 1) * float(T) * N * (4 * F * 4 + F * 4),
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches, "launches_per_step": rec_launches / K,
                 "note": "algorithmic fp32-equivalent FLOPs; f16x3 issues 3 fp16 MFMA products per FLOP pair, "
                         "f16f8 one fp16 product + one block-scaled FP8 MFMA (2x rate) for both corrections"}
