@@ -137,6 +137,7 @@ struct xb_ctx {
     int cap = 0;                                // chunks the workspaces hold (2 * max_batch when fusing is possible)
     Call held;
     bool holding = false, flushing = false;
+    int deferred_rc = 0;                        // failure of a held-back call that was launched where no status could be returned
     int8_t *fseq = nullptr;                     // (cap, T) / (cap) results of a fused pair before they are split
     int32_t *flen = nullptr;
 
@@ -989,6 +990,8 @@ XB_API int xb_synchronize(xb_ctx *ctx)
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
     int rc = flush_held(ctx);
+    if (!rc && ctx->deferred_rc) rc = ctx->deferred_rc;
+    ctx->deferred_rc = 0;
     if (rc) return rc;
     rc = sync_all(ctx);
     if (rc) return rc;
@@ -1452,12 +1455,20 @@ int flush_held(xb_ctx *ctx)
     ctx->holding = false;
     const int rc = launch_calls(ctx, h, nullptr);
     ctx->flushing = false;
-    if (rc) ctx->pipeline_failed = true;        // the call itself had already returned XB_OK
+    if (rc) {                                   // the call itself had already returned XB_OK
+        ctx->pipeline_failed = true;
+        ctx->deferred_rc = rc;                  // ... so the next call that can return a status reports it
+    }
     return rc;
 }
 
 static int enqueue_call(xb_ctx *ctx, const xb_ctx::Call &c)
 {
+    if (ctx->deferred_rc) {
+        const int rc = ctx->deferred_rc;
+        ctx->deferred_rc = 0;
+        return rc;               // xb_last_error still holds the message of the launch that failed
+    }
     if (ctx->holding) {
         const xb_ctx::Call h = ctx->held;
         ctx->holding = false;
