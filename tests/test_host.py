@@ -591,3 +591,27 @@ def test_eval_loop_handoff_fastq_to_paf_tooling():
         assert rid in recs and row[col["read_length"]] == len(recs[rid][0])
         assert all(q == 46 for q in recs[rid][1])                    # 'O': the Viterbi branch's constant quality (basecall.py:68)
         assert row[col["cs"]].startswith(":10*ag:") and row[col["strand"]] in "+-"
+
+
+def test_bench_traffic_is_the_committed_bytes_per_step_over_this_runs_launches():
+    """bench.py's roofline.traffic: the PMC passes (profiles/*_pmc_hbm_traffic.json) count bytes over `steps` bench steps with
+    whatever launch structure the profiled run had; the bench line divides the per-step bytes by ITS OWN launches per step, and
+    only for the configuration the passes were taken on."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True)[0]
+    d = json.load(open(path))
+    c = d["config"]
+    name = next(k for k in d["kernels"] if k.startswith("lstm_kernel"))
+    per_step = d["kernels"][name]["hbm_bytes_all_launches"] / d["steps"]
+    got = bench.measured_traffic("lstm_kernel", c["n_base"], c["batch_per_gpu"], c["chunksize"], c["precision"], 2.5)
+    assert got == pytest.approx(per_step / 2.5)
+    assert bench.measured_traffic("lstm_kernel", c["n_base"], c["batch_per_gpu"] + 1, c["chunksize"], c["precision"], 2.5) is None
+    # the recurrence's measured bytes stay close to what it has to move (gin in, layer output out)
+    T, N, F = c["chunksize"] // 5, c["batch_per_gpu"], 768
+    algorithmic_per_step = 5.0 * T * N * (4 * F * 4 + F * 4)
+    assert 1.0 <= per_step / algorithmic_per_step < 1.15
