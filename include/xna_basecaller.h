@@ -255,6 +255,8 @@ XB_API void *xb_result_stream(xb_ctx *ctx);
 typedef struct xb_comm xb_comm;
 XB_API int xb_comm_unique_id(char id[XB_COMM_ID_BYTES]);
 XB_API int xb_comm_create(xb_comm **out, int device, int rank, int world, const char id[XB_COMM_ID_BYTES]);
+/* xb_comm_destroy: after xb_synchronize of every context the communicator gathered for (a gather can be waiting for a
+ * held-back basecall of that context, see the header comment on co-scheduling). */
 XB_API void xb_comm_destroy(xb_comm *comm);
 XB_API int xb_comm_rank(const xb_comm *comm);
 XB_API int xb_comm_world(const xb_comm *comm);
