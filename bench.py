@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--nbase", type=int, default=6, choices=[4, 5, 6])
     ap.add_argument("--features", type=int, default=768)
-    ap.add_argument("--precision", default="f16f8", choices=["f16x3", "f16", "f16f8", "f16f8i"])
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "f16x3", "f16", "f16f8", "f16f8i"],
+                    help="mixed (the product default): feed-forward projections in f16x3, recurrent ones in f16f8")
     ap.add_argument("--cpu-chunks", type=int, default=64, help="chunks in the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--lstm-mode", type=int, default=0)
@@ -121,8 +122,7 @@ def main():
     nb, L, N, F = args.nbase, args.chunksize, args.batch, args.features
     alphabet = "NACGTXY"[:nb + 1]
     S, E = nb ** 3, nb + 1
-    prec = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8,
-            "f16f8i": _lib.XB_PREC_F16F8_IN1}[args.precision]
+    prec = _lib.PRECISIONS[args.precision]
     ctx = _lib.Context(local, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=prec, lstm_mode=args.lstm_mode)
     sd = peaky_weights(F, nb) if args.weights == "peaky" else seeded_weights(F, nb)
     ctx.load_state_dict(sd)
@@ -224,12 +224,12 @@ def main():
     chunks_per_launch_factor = 5.0 * K / max(rec_launches, 1)       # calls served per recurrence launch of a layer (time slabs: < 1)
     fused = chunks_per_launch_factor > 1.5
     dual = (N > 512 or fused) and os.environ.get("XB_LSTM_DUAL", "1") != "0"
-    roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2}[prec], "true" if dual else "false"),
+    roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false"),
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
                 "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K)),
-                # what a launch has to move: its gin tiles in (fp32, 4F per chunk and step), the layer output out (hi + q8 image)
+                # what a launch has to move: its gin tiles in (fp32, 4F per chunk and step), the layer output out (hi + second part)
                 "algorithmic_bytes": 5.0 * K / max(rec_launches, 1) * float(T) * N * (4 * F * 4 + F * 4),
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches, "launches_per_step": rec_launches / K,
                 "note": "algorithmic fp32-equivalent FLOPs; f16x3 issues 3 fp16 MFMA products per FLOP pair, "
@@ -253,7 +253,9 @@ def main():
         "dtype": {0: "f32 (split-f16x3 MFMA, f32 accumulate; CRF decode f32)",
                   1: "f16 MFMA, f32 accumulate; CRF decode f32",
                   2: "f32 (f16 MFMA + FP8 block-scaled correction MFMA, f32 accumulate; CRF decode f32)",
-                  3: "f32 (as f16f8, LSTM input projections f16 MFMA only, f32 accumulate; |score err| <= 1e-3; CRF decode f32)"}[prec],
+                  3: "f32 (as f16f8, LSTM input projections f16 MFMA only, f32 accumulate; |score err| <= 1e-3; CRF decode f32)",
+                  4: "f32 (feed-forward projections split-f16x3 MFMA, recurrent projections f16 MFMA + FP8 block-scaled correction "
+                     "MFMA, f32 accumulate; CRF decode f32)"}[prec],
         "data": "synthetic N(0,1) signal chunks generated in HBM; " +
                 ("seeded N(0,1/sqrt(fan_in)) weights in the reference state-dict layout" if args.weights == "seeded" else
                  "synthetic.peaky_weights (zero LSTM biases, input gain 2, CRF linear gain 10 / bias -2) in the reference state-dict layout"),

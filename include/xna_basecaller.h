@@ -27,12 +27,16 @@
  *     freeing the buffers passed in.  Consecutive xb_basecall_chunks_dev calls pipeline (decode of batch k overlaps
  *     the encoder of batch k+1): give each in-flight batch its own d_seq / d_seq_len -- and its own d_signal that
  *     stays untouched until xb_synchronize (or until work ordered behind xb_result_stream has run).
- *   - two batches in flight are CO-SCHEDULED (contexts of at most 512 chunks; XB_FUSE=0 switches it off): an
- *     xb_basecall_chunks_dev / xb_submit_chunks that finds nothing held back is itself held back (nothing is enqueued yet)
- *     until the next such call arrives; the two batches then go through the encoder and the decode as one -- the recurrence
- *     serves two chunk groups per workgroup and hides one group's hand-off behind the other's arithmetic -- and each
- *     call's results land in its own buffers.  A held-back call is launched on its own by every other entry point,
- *     by xb_synchronize, xb_result_stream and xb_collect_chunks of its slot; results are the same bytes either way.
+ *   - a caller that keeps two batches in flight can have them CO-SCHEDULED: after xb_reserve_pairing (an explicit opt-in;
+ *     contexts of at most 512 chunks; XB_FUSE=0 refuses) an xb_basecall_chunks_dev / xb_submit_chunks that finds nothing
+ *     held back is itself held back (NOTHING is enqueued yet -- a device-wide synchronise or an event recorded on a stream
+ *     fetched earlier does not cover it; its launch status is reported by the call that launches it) until the next such call
+ *     arrives; the two batches then go through the encoder and the decode as one -- the recurrence serves two chunk groups
+ *     per workgroup and hides one group's hand-off behind the other's arithmetic -- and each call's results land in its own
+ *     buffers.  A held-back call is launched on its own, with the weights and the profiling state it was called under, by
+ *     every other entry point (xb_load_weights, xb_weights_ready and xb_set_profiling included), by xb_synchronize,
+ *     xb_result_stream, xb_collect_chunks of its slot and xb_ctx_destroy; results are the same bytes either way.  Without the
+ *     opt-in every asynchronous call is enqueued before it returns.
  *   - layouts are the reference's: signal (N, L) fp32 [= (N,1,L)], scores (T, N, C) fp32
  *     time-major, labels / seq (N, T) int8.
  */
@@ -68,8 +72,13 @@ typedef enum xb_precision {
     XB_PREC_F16X3 = 0,        /* split-fp16 MFMA, 3 products, fp32 accumulate: |score err| ~3e-6 */
     XB_PREC_F16 = 1,          /* single fp16 MFMA, fp32 accumulate (the reference's model.half()): ~1e-3 */
     XB_PREC_F16F8 = 2,        /* fp16 main product + both correction products on the block-scaled FP8 MFMA: ~4e-5 */
-    XB_PREC_F16F8_IN1 = 3     /* as F16F8, but the LSTM input projections (45 % of the FLOPs, no feedback through time) keep
+    XB_PREC_F16F8_IN1 = 3,    /* as F16F8, but the LSTM input projections (45 % of the FLOPs, no feedback through time) keep
                                  only the fp16 main product: |score err| ~6e-4 max / 1e-4 rms, 1.19x the throughput */
+    XB_PREC_MIXED = 4         /* the feed-forward projections (conv3, the five LSTM input projections, the CRF linear layer) in
+                                 the three-product F16X3 arithmetic, the five recurrent projections (W_hh register-resident,
+                                 the critical path) in F16F8.  Default of Model, the CLI and bench.py: |score err| 3.4e-4 max on
+                                 trained-like (peaky) weights, where plain F16F8 sits on the 1e-3 tolerance (1.08e-3), at 0.87x
+                                 its throughput (profiles/r04_x3_attribution.txt) */
 } xb_precision;
 
 /*
@@ -204,21 +213,27 @@ XB_API int xb_basecall_chunks(xb_ctx *ctx, const float *signal, int n, const cha
                               int8_t *seq, int32_t *seq_len);
 XB_API int xb_basecall_chunks_dev(xb_ctx *ctx, const float *d_signal, int n, const char *alphabet,
                                   int8_t *d_seq, int32_t *d_seq_len);
-/* Room for two co-scheduled calls (see the header comment): a context allocates workspaces for max_batch chunks and replaces
- * them by twice that the first time two calls are paired -- which waits for everything in flight and takes a second or two.
- * A caller that will keep two batches in flight can have that done up front (bench.py does, outside its timed region).
- * XB_OK also when the context does not pair calls (XB_FUSE=0, max_batch > 512, serial schedule). */
+/* Opt in to the co-scheduling of two calls in flight (see the header comment) and make room for it: the workspaces for
+ * max_batch chunks are replaced by twice that -- which waits for everything in flight and takes a second or two, so callers
+ * do it once, up front (bench.py: outside its timed region; Model: when the host pipeline starts).  XB_OK also when the
+ * context cannot pair calls (XB_FUSE=0, max_batch > 512, serial schedule): xb_pairing_active tells (1: asynchronous calls
+ * may be held back for a partner from now on; 0: every call is enqueued before it returns).  XB_ERR_NOMEM: no room for a
+ * pair -- the context carries on unpaired.  No counterpart in the reference (single batch in flight, crf/basecall.py:109-111). */
 XB_API int xb_reserve_pairing(xb_ctx *ctx);
+XB_API int xb_pairing_active(const xb_ctx *ctx);
 
 /*
  * The same operator for a host pipeline that keeps the device busy (crf/basecall.py:96-119: the reference overlaps its
  * stages with threads and bounded queues; here the overlap is two batches in flight on the device).
- * xb_submit_chunks copies `signal` (n, L) into pinned staging of `slot` (0 or 1), enqueues H2D on a copy stream, the
- * fused encode + decode, and the D2H of the results into pinned staging, and returns without waiting.
+ * xb_submit_chunks copies `signal` (n, L) into pinned staging of `slot` (0 .. XB_PIPELINE_SLOTS - 1), enqueues H2D on a
+ * copy stream, the fused encode + decode, and the D2H of the results into pinned staging, and returns without waiting.
  * xb_collect_chunks waits for that slot's batch only and copies seq (n, T) / seq_len (n) out.  Typical use: submit
- * batch k+1 into the other slot, then collect batch k -- results arrive one batch late, in order.
+ * batch k+1 into the next slot, then collect batch k -- results arrive one batch late, in order; with co-scheduled pairs
+ * (xb_reserve_pairing) rotate all four slots -- submit batch k+3, then collect batch k -- so that pair (k+2, k+3) is on the
+ * device before the host waits for pair (k, k+1).
  * A slot must be collected before it is submitted again (XB_ERR_STATE otherwise).
  */
+#define XB_PIPELINE_SLOTS 4
 XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, const char *alphabet);
 XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_len);
 
@@ -291,6 +306,11 @@ XB_API int xb_get_stage_times(xb_ctx *ctx, float ms[XB_STAGE_COUNT], int64_t lau
 XB_API int xb_reset_stage_times(xb_ctx *ctx);
 /* Output time steps per chunk, states, score columns of the loaded config. */
 XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_noblank);
+/* Diagnostic, no counterpart in the reference (tests of the mixed-precision encoder, XB_PREC_MIXED): the activations the
+ * last xb_encode / xb_encode_dev of n chunks left on the device -- which = 0: output of LSTM layer 3 (nn.py:216-220, module
+ * encoder.7), 1: of LSTM layer 4 (encoder.8) -- as (T, n, features) fp16 bit patterns `hi` plus the raw second part (2 bytes per
+ * element: the fp16 residual, or the q8 image of DESIGN.md 2, whichever the consuming stage's arithmetic reads). */
+XB_API int xb_debug_layer_output(xb_ctx *ctx, int which, int n, uint16_t *hi, uint16_t *second);
 XB_API const char *xb_version(void);
 
 #ifdef __cplusplus

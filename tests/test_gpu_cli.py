@@ -126,3 +126,39 @@ def test_cli_reads_fast5_like_bundles(tmp_path):
         assert r.returncode == 0, r.stderr.decode()
         outs[kind] = out.read_text().replace("f5:Z:batch_0.fast5", "f5:Z:X").replace("f5:Z:batch_0.xsig.npz", "f5:Z:X")
     assert outs["f5"] == outs["npz"] and outs["f5"].count("\n") == 32
+
+
+def test_cli_sam_text_output_of_the_beam_branch(tmp_path):
+    """`bonito basecaller MODEL READS > calls.sam` (io.py:30-49: the extension of stdout's target selects SAM) on a 4-base model,
+    whose default decode is the beam search with real quality strings: header (@HD, @PG basecaller, one @RG per run), one
+    unaligned record per read (flag 4), the same sequences / qualities / tags as the FASTQ of the same run."""
+    labels = list("NACGT")
+    model_dir = str(tmp_path / "dna_test@v1")
+    reads_dir = str(tmp_path / "reads")
+    _make_model_dir(model_dir, 64, labels, seed=5)
+    _make_reads(reads_dir, 6)
+    outs = {}
+    for ext in ("sam", "fastq"):
+        out = tmp_path / ("calls." + ext)
+        with open(out, "w") as fh:
+            r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir, "--batch", "7", "-v"],
+                               cwd=ROOT, stdout=fh, stderr=subprocess.PIPE, timeout=600)
+        err = r.stderr.decode()
+        assert r.returncode == 0, err
+        assert "> outputting unaligned %s" % ext in err and "> decode algorithm: Beam Search" in err
+        outs[ext] = out.read_text()
+    lines = outs["sam"].splitlines()
+    head = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    assert head[0] == "@HD\tVN:1.5\tSO:unknown\tob:0.0.1"
+    assert head[1].startswith("@PG\tID:basecaller\tPN:bonito\tVN:") and ("CL:bonito basecaller %s %s" % (model_dir, reads_dir)) in head[1]
+    assert head[2:] == ["@RG\tID:runX_%s\tPL:ONT\tDT:2021-06-01T10:00:00\tPU:\tPM:None\tLB:None\tSM:None\tDS:run_id=runX basecall_model=%s"
+                        % (model_dir, model_dir)]
+    fq = outs["fastq"].strip().split("\n")
+    assert len(body) == 6 == len(fq) // 4
+    for rec, hdr, seq, qs in zip(body, fq[0::4], fq[1::4], fq[3::4]):
+        f = rec.split("\t")
+        assert f[1:9] == ["4", "*", "0", "0", "*", "*", "0", "0"] and f[11] == "NM:i:0"
+        assert f[9] == seq and f[10] == qs and len(set(qs)) > 1          # real qualities, not the Viterbi branch's placeholder
+        assert "@" + f[0] + " " + "\t".join(f[12:]) == hdr
+    assert (tmp_path / "calls_summary.tsv").read_text().count("\n") == 2 * 6 + 1     # both runs appended their rows

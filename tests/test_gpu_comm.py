@@ -13,13 +13,18 @@ from xna_basecaller_amd import dist as xdist
 pytestmark = pytest.mark.gpu
 
 
-def test_gather_called_one_rank_roundtrip():
+@pytest.mark.parametrize("pairing", [False, True])
+def test_gather_called_one_rank_roundtrip(pairing):
+    """pairing: the asynchronous calls are co-scheduled two by two (xb_reserve_pairing, bench.py's schedule), so every other
+    gather is asked for while its basecall is still held back and runs right behind that call's launch."""
     import torch
     F, nb, L, N = 64, 6, 1000, 40
     keys, shapes = encoder_shapes(F, nb)
     sd = seeded_state_dict(keys, shapes, seed=3)
     ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
     ctx.load_state_dict(sd)
+    if pairing:
+        assert ctx.reserve_pairing()
     T = ctx.T
     g = xdist.RcclGather(ctx, 0, 0, 1)
     assert g.comm.rank == 0 and g.comm.world == 1

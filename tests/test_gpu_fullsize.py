@@ -22,7 +22,7 @@ F, L, SL = 768, 10000, 3
 def _run(nb, N, d_signal, n_calls):
     """Fused basecall of the resident batch `n_calls` times back to back (one synchronize at the end)."""
     import torch
-    ctx = _lib.Context(0, nb, SL, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
+    ctx = _lib.Context(0, nb, SL, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_MIXED)     # the default of bench.py / Model
     keys, shapes = encoder_shapes(F, nb)
     ctx.load_state_dict(seeded_state_dict(keys, shapes, seed=25))
     dev = d_signal.device
@@ -108,18 +108,26 @@ def test_slab_signalling_recurrence_equals_one_launch_per_slab(monkeypatch):
     assert np.array_equal(seqs0[0], seqs[0]) and np.array_equal(lens0[0], lens[0])
 
 
-@pytest.mark.parametrize("nb", [5, 6])
-def test_end_to_end_labels_on_the_peaky_model(nb):
-    """VERDICT r2 (weak 2 / next 3): with the plain seeded weights the posteriors are flat and the end-to-end comparison above
-    is vacuous.  synthetic.peaky_weights gives the regime of a trained model at the timed size (features 768, T 2000, N 512):
-    scores that follow the signal, ~0.35-0.5 bases called per time step.  The whole GPU path (encoder + decode, default
-    precision f16f8) against the whole oracle path (fp32 encoder + decode), 32 sampled chunks = 64 000 time steps:
+# precision -> (max |score error|, rms) allowed on the peaky model at the timed size.  "mixed" is the default of Model, the CLI
+# and bench.py and has to meet the north star's 1e-3 with margin (measured 3.4e-4 max / 2.6e-5 rms at nb 6, target <= 5e-4);
+# plain f16f8 is the faster opt-in and keeps its own, wider bound (measured 1.08e-3 / 8.1e-5: ON the tolerance).
+PEAKY_BOUNDS = {"mixed": (5e-4, 5e-5), "f16f8": (2.5e-3, 2e-4)}
+
+
+@pytest.mark.parametrize("nb,precision", [(6, "mixed"), (5, "mixed"), (6, "f16f8")])
+def test_end_to_end_labels_on_the_peaky_model(nb, precision):
+    """VERDICT r2 (weak 2 / next 3), r3 (next 1): with the plain seeded weights the posteriors are flat and the end-to-end
+    comparison above is vacuous.  synthetic.peaky_weights gives the regime of a trained model at the timed size (features 768,
+    T 2000, N 512): scores that follow the signal, ~0.35-0.5 bases called per time step.  The whole GPU path (encoder + decode)
+    against the whole oracle path (fp32 encoder + decode), 32 sampled chunks = 64 000 time steps:
       * the GPU decode of the GPU's scores is the oracle's decode of them, exactly (as everywhere);
-      * CRF scores within the north star's 1e-3 + margin (this model is ~15x more sensitive to rounding than the plain
-        seeded one: measured 1.0e-3 max / 8e-5 rms; plain model 4e-5 max);
-      * label mismatch GPU path vs all-oracle path <= 1.5e-3 (measured 3.8e-4 at nb 6, 5.1e-4 at nb 5; the three-product
-        f16x3 arithmetic, 15x closer in the scores, still differs on 2.5e-4 / 3.8e-4: what is left are the exact and
-        near-exact score ties of saturated 5 tanh edges, which ANY difference in the last bit re-orders -- tools/peaky_parity.py);
+      * CRF scores within PEAKY_BOUNDS of the fp32 oracle -- this model is ~15x more sensitive to rounding than the plain
+        seeded one, and its error is spread over all stages (profiles/r04_x3_attribution.txt: of plain f16f8's error variance the
+        input projections make 65 %, the linear layer 18 %, the recurrences 13 %, conv3 5 %), hence the default arithmetic
+        "mixed": every feed-forward projection in three fp16 products;
+      * label mismatch GPU path vs all-oracle path <= 1.5e-3 (f16f8: measured 3.8e-4 at nb 6, 5.1e-4 at nb 5; even f16x3,
+        15x closer in the scores, still differs on 2.5e-4 / 3.8e-4: what is left are the exact and near-exact score ties of
+        saturated 5 tanh edges, which ANY difference in the last bit re-orders -- tools/peaky_parity.py);
       * called length per chunk within +-8 bases of the oracle's, the same on at least 60 % of the chunks.
     """
     import torch
@@ -127,7 +135,7 @@ def test_end_to_end_labels_on_the_peaky_model(nb):
     N, npick = 512, 32
     alphabet = "NACGTXY"[:nb + 1]
     sd = peaky_weights(F, nb)
-    ctx = _lib.Context(0, nb, SL, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
+    ctx = _lib.Context(0, nb, SL, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.PRECISIONS[precision])
     ctx.load_state_dict(sd)
     T = ctx.T
     gen = torch.Generator(device="cuda")
@@ -153,13 +161,41 @@ def test_end_to_end_labels_on_the_peaky_model(nb):
     gseq, _, glen = oracle.pack(lab_g, alphabet)
     assert np.array_equal(glen, lens[picks]) and np.array_equal(gseq, seqs)
     ref = oracle.encode(x, sd, F, nb, SL, expand_blanks=False)
-    assert float(np.abs(ref - sc).max()) < 2.5e-3
-    assert float(np.sqrt(((ref - sc) ** 2).mean())) < 2e-4
+    emax, erms = PEAKY_BOUNDS[precision]
+    assert float(np.abs(ref - sc).max()) < emax
+    assert float(np.sqrt(((ref - sc).astype(np.float64) ** 2).mean())) < erms
     lab_o = oracle.decode(ref, nb, SL, blank_score=2.0)["labels"]
     _, _, olen = oracle.pack(lab_o, alphabet)
     mismatch = float((lab_o != lab_g).mean())
     assert mismatch <= 1.5e-3, mismatch
     assert np.abs(olen - glen).max() <= 8 and (olen == glen).mean() >= 0.6
+
+
+@pytest.mark.parametrize("nb", [5, 6])
+def test_default_precision_on_the_seeded_model_at_the_timed_size(nb):
+    """The same bound (1e-3 with margin: < 5e-4; measured 3e-5) for the default arithmetic on the plain seeded weights at
+    features 768, T 2000, N 512 -- the model bench.py times."""
+    import torch
+    N, npick = 512, 12
+    keys, shapes = encoder_shapes(F, nb)
+    sd = seeded_state_dict(keys, shapes, seed=25)
+    ctx = _lib.Context(0, nb, SL, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_MIXED)
+    ctx.load_state_dict(sd)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    d_signal = torch.randn((N, L), dtype=torch.float32, device="cuda", generator=gen)
+    d_scores = torch.empty((ctx.T, N, ctx.C_noblank), dtype=torch.float32, device="cuda")
+    ctx.encode_dev(d_signal.data_ptr(), N, False, d_scores.data_ptr())
+    ctx.synchronize()
+    picks = np.linspace(0, N - 1, npick).astype(int)
+    sc = d_scores[:, picks, :].cpu().numpy()
+    x = d_signal[picks].cpu().numpy()
+    del d_scores
+    ctx.close()
+    ref = oracle.encode(x, sd, F, nb, SL, expand_blanks=False)
+    err = float(np.abs(ref - sc).max())
+    assert err < 5e-4, err
+    assert err < 1e-4, err              # what it delivers here
 
 
 def test_compute_scores_reverse():

@@ -109,9 +109,10 @@ def test_pipelined_device_calls_match_blocking_calls():
 
 
 def test_two_calls_in_flight_share_one_pass(monkeypatch):
-    """XB_FUSE (default on for contexts of at most 512 chunks): the first of two asynchronous calls is held back and both go
-    through the encoder and the decode as one batch -- half the recurrence launches, the same bytes as with XB_FUSE=0; a held
-    call is launched on its own by xb_result_stream / xb_synchronize / any other entry point, and a lone last call too."""
+    """Co-scheduling of two calls in flight (xb_reserve_pairing opts in; contexts of at most 512 chunks): the first of two
+    asynchronous calls is held back and both go through the encoder and the decode as one batch -- half the recurrence launches,
+    the same bytes as without; a held call is launched on its own by xb_result_stream / xb_synchronize / any other entry point,
+    and a lone last call too.  Without the opt-in (and with XB_FUSE=0 even after it) every call is enqueued on its own."""
     import torch
     from conftest import encoder_shapes, seeded_state_dict
     from xna_basecaller_amd import _lib
@@ -124,10 +125,13 @@ def test_two_calls_in_flight_share_one_pass(monkeypatch):
     rng = np.random.default_rng(12)
     d_in = [torch.from_numpy(rng.standard_normal((N, L)).astype(np.float32)).to(dev) for _ in range(5)]
 
-    def run(fuse, poke):
+    def run(fuse, poke, opt_in=True):
         monkeypatch.setenv("XB_FUSE", fuse)
         ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_F16F8)
         ctx.load_state_dict(sd)
+        assert not ctx.pairing_active()
+        if opt_in:
+            assert ctx.reserve_pairing() == (fuse == "1")
         d_seq = [torch.full((N, ctx.T), -1, dtype=torch.int8, device=dev) for _ in d_in]
         d_len = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in d_in]
         ctx.set_profiling(True)
@@ -149,12 +153,46 @@ def test_two_calls_in_flight_share_one_pass(monkeypatch):
         return out, launches
 
     ref, n_ref = run("0", False)
+    plain, n_plain = run("1", False, opt_in=False)
     got, n_got = run("1", False)
     poked, n_poked = run("1", True)
-    assert n_ref == 5 and n_got == 3 and n_poked == 3          # (0,1) (2,3) 4  /  0 (1,2) (3,4)
-    for (rs, rl), (gs, gl), (ps, pl) in zip(ref, got, poked):
+    assert n_ref == 5 and n_plain == 5 and n_got == 3 and n_poked == 3          # (0,1) (2,3) 4  /  0 (1,2) (3,4)
+    for (rs, rl), (gs, gl), (ps, pl), (qs, ql) in zip(ref, got, poked, plain):
         assert np.array_equal(rs, gs) and np.array_equal(rl, gl)
         assert np.array_equal(rs, ps) and np.array_equal(rl, pl)
+        assert np.array_equal(rs, qs) and np.array_equal(rl, ql)
+
+
+def test_held_call_keeps_the_weights_it_was_called_with():
+    """a held-back call must run with the weight set (and the profiling state) in force when it was made: loading new
+    weights first launches it."""
+    import torch
+    from conftest import encoder_shapes, seeded_state_dict
+    from xna_basecaller_amd import _lib
+    F, nb, L, N = 64, 6, 1500, 20
+    keys, shapes = encoder_shapes(F, nb)
+    sd_a, sd_b = seeded_state_dict(keys, shapes, seed=1), seeded_state_dict(keys, shapes, seed=2)
+    alphabet = "NACGTXY"
+    x = np.random.default_rng(0).standard_normal((N, L)).astype(np.float32)
+    ctx = _lib.Context(0, nb, 3, F, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_MIXED)
+    ctx.load_state_dict(sd_a)
+    want_a = ctx.basecall_chunks(x, alphabet)
+    assert ctx.reserve_pairing()
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(x).to(dev)
+    d_seq = torch.full((N, ctx.T), -1, dtype=torch.int8, device=dev)
+    d_len = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    ctx.basecall_chunks_dev(d_x.data_ptr(), N, alphabet, d_seq.data_ptr(), d_len.data_ptr())      # held back
+    ctx.load_state_dict(sd_b)                                                                     # launches it with weights A first
+    ctx.synchronize()
+    assert np.array_equal(d_seq.cpu().numpy(), want_a[0]) and np.array_equal(d_len.cpu().numpy(), want_a[1])
+    want_b = ctx.basecall_chunks(x, alphabet)
+    assert not np.array_equal(want_a[0], want_b[0])
+    # a held call at destruction is launched (its deferred gather would be a collective) and waited for, not dropped
+    ctx.basecall_chunks_dev(d_x.data_ptr(), N, alphabet, d_seq.data_ptr(), d_len.data_ptr())
+    ctx.close()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_seq.cpu().numpy(), want_b[0])
 
 
 def test_submit_collect_pipeline_matches_blocking_calls():
@@ -180,9 +218,31 @@ def test_submit_collect_pipeline_matches_blocking_calls():
     got.append(ctx.collect_chunks(*pending))
     for (es, el), (gs, gl) in zip(expect, got):
         assert np.array_equal(el, gl) and np.array_equal(es, gs)
+    # four slots, co-scheduled pairs: submit k+3 before collecting k (the product pipeline's rotation)
+    assert ctx.reserve_pairing()
+    got, pending, slot = [], [], 0
+    ctx.set_profiling(True)
+    ctx.reset_stage_times()
+    for x in [b.copy() for b in (rng.standard_normal((n, L)).astype(np.float32) for n in (40, 17, 40, 1, 33, 40, 5))]:
+        pending.append((slot, ctx.submit_chunks(slot, x, alphabet), x.copy()))
+        x[:] = 0
+        slot = (slot + 1) % _lib.XB_PIPELINE_SLOTS
+        if len(pending) == _lib.XB_PIPELINE_SLOTS:
+            s_, n_, x_ = pending.pop(0)
+            got.append((ctx.collect_chunks(s_, n_), x_))
+    for s_, n_, x_ in pending:
+        got.append((ctx.collect_chunks(s_, n_), x_))
+    assert ctx.stage_times()["decode"][1] == 4          # 7 batches = 3 pairs + 1
+    ctx.set_profiling(False)
+    for (gs, gl), x_ in got:
+        es, el = ctx.basecall_chunks(x_, alphabet)
+        assert np.array_equal(el, gl) and np.array_equal(es, gs)
     with pytest.raises(_lib.XbError) as e:
         ctx.collect_chunks(0, 1)                  # nothing in flight
     assert e.value.code == -4
+    with pytest.raises(_lib.XbError) as e:
+        ctx.submit_chunks(_lib.XB_PIPELINE_SLOTS, batches[1][:3], alphabet)     # no such slot
+    assert e.value.code == -1
     ctx.submit_chunks(1, batches[1][:3] + 1.0, alphabet)
     with pytest.raises(_lib.XbError) as e:
         ctx.submit_chunks(1, batches[1][:3], alphabet)     # slot still in flight

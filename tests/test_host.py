@@ -615,3 +615,189 @@ def test_bench_traffic_is_the_committed_bytes_per_step_over_this_runs_launches()
     T, N, F = c["chunksize"] // 5, c["batch_per_gpu"], 768
     algorithmic_per_step = 5.0 * T * N * (4 * F * 4 + F * 4)
     assert 1.0 <= per_step / algorithmic_per_step < 1.15
+
+
+class _FakePipelineModel:
+    """Host-logic stand-in for Model in compute_sequences_pipelined: records the submit / collect order, enforces the C ABI's
+    slot rule (a slot is collected before it is submitted again) and returns each batch's own first column as its 'sequence'."""
+
+    class _Enc:
+        expand_blanks = True
+
+    def __init__(self, depth, max_batch=8):
+        self.encoder = [self._Enc()]
+        self.depth, self.max_batch = depth, max_batch
+        self.geometry = None
+        self.busy = {}
+        self.log = []
+        self.rebuilds = 0
+
+    def context_is_current(self, chunk_len, batch):
+        return self.geometry == chunk_len and batch <= self.max_batch
+
+    def pipeline_depth(self, chunk_len, n):
+        if not self.context_is_current(chunk_len, n):
+            assert not self.busy, "context rebuilt with batches in flight"
+            self.geometry = chunk_len
+            self.rebuilds += 1
+        return self.depth
+
+    def submit_chunks(self, slot, batch):
+        assert self.context_is_current(batch.shape[-1], batch.shape[0])
+        assert 0 <= slot < self.depth and slot not in self.busy, "slot %d submitted twice" % slot
+        self.busy[slot] = np.asarray(batch)[:, 0, :1].astype(np.int8).copy()
+        self.log.append(("submit", slot))
+        return ("ctx", slot, batch.shape[0])
+
+    def collect_chunks(self, handle):
+        _, slot, n = handle
+        self.log.append(("collect", slot))
+        seq = self.busy.pop(slot)
+        return seq, np.ones(n, np.int32)
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_device_stage_keeps_depth_batches_in_flight_in_order(depth):
+    """crf/basecall.py:109-111 (compute_scores stage): results in input order; `depth` batches rotate through `depth` staging
+    slots (4 where the context co-schedules two calls per pass: pair k+1 is submitted before pair k is collected); a change of
+    geometry drains everything first."""
+    from xna_basecaller_amd.crf.basecall import compute_sequences_pipelined
+    model = _FakePipelineModel(depth)
+    sizes = [8, 8, 3, 8, 8, 8, 1] + [8] * 4
+    lens = [100] * 7 + [60] * 4                                   # the last four batches need another context
+    batches = [("k%d" % i, np.full((n, 1, L), i, np.float32)) for i, (n, L) in enumerate(zip(sizes, lens))]
+    out = list(compute_sequences_pipelined(model, iter(batches)))
+    assert [k for k, _ in out] == [k for k, _ in batches]
+    for i, (_, seq) in enumerate(out):
+        assert seq.shape == (sizes[i], 1) and np.all(seq == i)
+    assert not model.busy and model.rebuilds == 2
+    # steady state: `depth` submits before the first collect, then they alternate; a collect always takes the oldest batch
+    first = model.log[:depth + 1]
+    assert first == [("submit", s) for s in range(depth)] + [("collect", 0)]
+    inflight, peak = 0, 0
+    for op, _ in model.log:
+        inflight += 1 if op == "submit" else -1
+        peak = max(peak, inflight)
+    assert peak == depth
+
+
+def test_sam_text_output_matches_the_reference_functions(tmp_path):
+    """SURVEY 8 f3 (second half): `> calls.sam`.  tests/golden/sam.json holds what the reference's own sam_header / sam_record
+    (unaligned branch) / Read.readgroup / Read.tagdata returned for four reads (make_sam_golden.py, build container): this
+    package's functions return the same strings, and Writer(mode 'w') writes header + one line per record."""
+    import io as pyio
+    import types
+    from xna_basecaller_amd import io as xio
+    from xna_basecaller_amd import reads as xreads
+    g = json.load(open(os.path.join(GOLDEN, "sam.json")))
+    model = g["model"]
+    rds = []
+    for rec in g["records"]:
+        r = types.SimpleNamespace(**rec["read"])
+        r.signal = np.zeros(100 + len(rec["sequence"]), np.float32)
+        r.start = r.duration = r.template_start = r.template_duration = 0.0
+        r.tagdata = (lambda r=r: xreads._read_tags(r))
+        rds.append(r)
+        assert r.tagdata() == rec["tags"][2:]
+        assert xio.sam_record(r.read_id, rec["sequence"], rec["qstring"], False, tags=rec["tags"]) == rec["sam_record"]
+        assert xio.sam_record(r.read_id, rec["sequence"], rec["qstring"], None) == rec["sam_record_no_tags"]
+    groups = sorted({xreads._read_group(r, model) for r in rds})
+    assert groups == g["groups"]
+    header = xio.sam_header(groups, version=g["bonito_version"], argv=g["argv"], aligner_version=g["mappy_version"])
+    assert header == g["header"]
+    # without an aligner (the only case here) the aligner's @PG line is not claimed; everything else is unchanged
+    plain = xio.sam_header(groups, version=g["bonito_version"], argv=g["argv"])
+    assert plain == "".join(l for l in g["header"].splitlines(True) if not l.startswith("@PG\tID:aligner"))
+    with pytest.raises(NotImplementedError):
+        xio.sam_record("r", "ACGT", "IIII", mapping=object())
+    # the writer: header first, then the records in order, an empty call skipped, summary rows as for FASTQ
+    out = pyio.StringIO()
+    results = [(r, {"sequence": rec["sequence"], "qstring": rec["qstring"], "mean_qscore": float(rec["tags"][1].split(":")[2])})
+               for r, rec in zip(rds, g["records"])]
+    results.insert(2, (rds[0], {"sequence": "", "qstring": ""}))
+    w = xio.Writer("w", iter(results), fd=out, group_key=model, groups=set(groups), summary=str(tmp_path / "s_summary.tsv"))
+    w.run()
+    text = out.getvalue()
+    assert text.startswith(xio.sam_header(groups))
+    body = text[len(xio.sam_header(groups)):].splitlines()
+    assert body == [rec["sam_record"] for rec in g["records"]]
+    for line in body:                                    # SAM: 11 mandatory columns, flag 4, unmapped placeholders
+        f = line.split("\t")
+        assert f[1] == "4" and f[2] == "*" and f[5] == "*" and len(f[9]) == len(f[10]) and f[11] == "NM:i:0"
+    assert len(open(tmp_path / "s_summary.tsv").read().splitlines()) == 1 + len(g["records"])
+    assert [rid for rid, _ in w.log] == [r.read_id for r in rds]
+    for mode in ("wb", "wc"):
+        with pytest.raises(NotImplementedError):
+            xio.Writer(mode, iter([]))
+
+
+def test_read_groups_from_bundles_without_touching_signals(tmp_path):
+    """cli/basecaller.py:100-106 / fast5.py:236-251: the @RG lines of the selected reads, metadata only."""
+    from xna_basecaller_amd import reads as xreads
+    recs = []
+    for i in range(5):
+        recs.append((np.zeros(10, np.int16), dict(read_id="r%d" % i, run_id="run%d" % (i % 2), range=1400.0, digitisation=8192.0,
+                                                  offset=3, sampling_rate=4000.0, sample_id="lib", flow_cell_id="FC%d" % (i % 2),
+                                                  device_id="MN1", exp_start_time="2021-03-04T05:06:07Z")))
+    xreads.write_bundle(str(tmp_path / "a.xsig.npz"), recs)
+    groups = xreads.get_read_groups(str(tmp_path), "m@v1")
+    assert groups == {"@RG\tID:run%d_m@v1\tPL:ONT\tDT:2021-03-04T05:06:07\tPU:FC%d\tPM:MN1\tLB:lib\tSM:lib\tDS:run_id=run%d basecall_model=m@v1"
+                      % (k, k, k) for k in (0, 1)}
+    assert xreads.get_read_groups(str(tmp_path), "m@v1", read_ids={"r0", "r2"}) == {g for g in groups if "run0" in g}
+
+
+def test_eval_loop_accuracy_table_from_this_packages_fastq(tmp_path):
+    """SURVEY 8 f2, the accuracy half (eval_model.sh:155-177 -> src/tools/analyze_paf.py).  tests/golden/evalacc.json holds
+    what the REFERENCE's compute_all_error_rates_paf / compute_stats_error_rate computed (build container) from (a) FASTQ text
+    written by this package's Writer for 33 designed calls on three POC templates and (b) the PAF minimap2 reports for them
+    (known alignments: UB called right / as a natural base / as the wrong UB / deleted / put beside its gap, both strands).
+    Here: the Writer still produces that FASTQ byte for byte, a strict FASTQ parse feeds the restated metrics
+    (tests/evalloop_metrics.py), and every number of the reference's table is reproduced -- per read, per template position,
+    and the UB / DNA accuracy cuts."""
+    import io
+    import evalloop_metrics as em
+    from xna_basecaller_amd import io as xio
+    from xna_basecaller_amd.reads import SyntheticRead
+    g = json.load(open(os.path.join(GOLDEN, "evalacc.json")))
+    out = io.StringIO()
+    results = []
+    for i, (rid, _, seq) in enumerate(g["reads"]):
+        r = SyntheticRead(rid, np.zeros(10 * len(seq), np.float32), run_id="evalrun", filename="poc.xsig.npz", channel=str(1 + i),
+                          mux=1 + i % 4, read_number=i)
+        results.append((r, {"sequence": seq, "qstring": "O" * len(seq), "mean_qscore": 40.0}))
+    xio.Writer("wfq", iter(results), fd=out, group_key="xna_r9.4.1_e8_sup@v3.3", summary=str(tmp_path / "x_summary.tsv")).run()
+    assert out.getvalue() == g["fastq"]
+    recs = out.getvalue().strip().split("\n")
+    assert len(recs) % 4 == 0 and all(l == "+" for l in recs[2::4]) and all(h.startswith("@") for h in recs[0::4])
+    seqs = {h[1:].split()[0]: s for h, s in zip(recs[0::4], recs[1::4])}
+    rows = em.parse_paf(g["paf"])
+    assert [r["read_id"] for r in rows] == [r["read_id"] for r in g["per_read"]]
+    by_group = {}
+    for row, want in zip(rows, g["per_read"]):
+        wrong, m = em.read_metrics(row, g["templates"][row["target_id"]], seqs[row["read_id"]])
+        by_group.setdefault("%s/%s" % (row["target_id"], row["strand"]), []).append(wrong)
+        for k, v in want.items():
+            if k in ("read_id", "target_id", "strand"):
+                continue
+            if v is None:
+                assert np.isnan(m[k]), (row["read_id"], k)
+            elif isinstance(v, str):
+                assert m[k] == v, (row["read_id"], k, m[k], v)
+            else:
+                assert abs(m[k] - v) < 1e-12, (row["read_id"], k, m[k], v)
+    assert sorted(by_group) == sorted(g["error_rate_per_position"])
+    for key, errs in by_group.items():
+        rate = np.mean(errs, axis=0) * 100
+        assert np.allclose(rate, g["error_rate_per_position"][key], rtol=0, atol=1e-12)
+        tid, strand = key.split("/")
+        t = g["templates"][tid]
+        ubs = [i for i, c in enumerate(t) if c == "N"]
+        if strand == "-":
+            ubs = [len(t) - p - 1 for p in ubs[::-1]]
+        cuts = em.error_rate_cuts(rate, ubs, max_dist=4)
+        assert sorted(cuts) == sorted(g["error_rate_cuts"][key])
+        for name, vals in g["error_rate_cuts"][key].items():
+            assert np.allclose(cuts[name], vals, rtol=0, atol=1e-12), (key, name)
+    # the headline numbers (README.md:139-143 reports them per model): UB accuracy = 100 - mean error at the UB, DNA = elsewhere
+    ub_acc = {k: 100 - np.mean(v["only_ub"]) for k, v in g["error_rate_cuts"].items()}
+    assert abs(ub_acc["XNA01/+"] - 100 * 4 / 7) < 1e-9 and abs(ub_acc["XNA01/-"] - 75.0) < 1e-9

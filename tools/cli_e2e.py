@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--features", type=int, default=768)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--fuse", default="", help="comma list of XB_FUSE values to run the CLI under, on the same reads (e.g. 1,0)")
     args = ap.parse_args()
     import torch
     from xna_basecaller_amd import reads as xreads, toml_lite
@@ -67,17 +68,30 @@ def main():
     print("wrote %d reads in %.1f s" % (args.reads, time.time() - t0), flush=True)
 
     out = os.path.join(work, "calls.fastq")
-    t0 = time.time()
-    with open(out, "w") as fh:
-        r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir], cwd=ROOT,
-                           stdout=fh, stderr=subprocess.PIPE)
-    wall = time.time() - t0
-    err = r.stderr.decode()
-    print(err[-1200:])
-    print("cli wall (incl. start-up and model load): %.1f s, rc %d, fastq %d bytes" % (wall, r.returncode, os.path.getsize(out)))
+    rc, digests = 0, []
+    for fuse in (args.fuse.split(",") if args.fuse else [None]):
+        env = dict(os.environ)
+        if fuse is not None:
+            env["XB_FUSE"] = fuse
+        t0 = time.time()
+        with open(out, "w") as fh:
+            r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir], cwd=ROOT,
+                               stdout=fh, stderr=subprocess.PIPE, env=env)
+        wall = time.time() - t0
+        err = r.stderr.decode()
+        print("== XB_FUSE=%s (reads %d x ~%d samples, batch %d)" % (fuse, args.reads, args.samples, args.batch))
+        print("\n".join(l for l in err.splitlines() if l.startswith(">"))[-1200:])
+        import hashlib
+        digests.append(hashlib.sha1(open(out, "rb").read()).hexdigest())
+        print("cli wall (incl. start-up and model load): %.1f s, rc %d, fastq %d bytes, sha1 %s"
+              % (wall, r.returncode, os.path.getsize(out), digests[-1][:12]), flush=True)
+        rc = rc or r.returncode
+    if len(set(digests)) > 1:
+        print("FASTQ differs between the schedules")
+        rc = rc or 1
     if not args.keep:
         shutil.rmtree(work, ignore_errors=True)
-    sys.exit(r.returncode)
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

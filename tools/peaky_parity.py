@@ -20,7 +20,7 @@ def main():
     F, L, N = 768, 10000, int(os.environ.get("PEAKY_N", "512"))
     npick = int(os.environ.get("PEAKY_PICKS", "24"))
     for nb in (6, 5):
-        for prec in (_lib.XB_PREC_F16F8, _lib.XB_PREC_F16X3):
+        for prec in (_lib.XB_PREC_MIXED, _lib.XB_PREC_F16F8, _lib.XB_PREC_F16X3):
             ig, lg, bb = 2.0, 10.0, 2.0
             alphabet = "NACGTXY"[:nb + 1]
             sd = peaky_weights(F, nb, input_gain=ig, linear_gain=lg, blank_bias=bb)
@@ -54,7 +54,7 @@ def main():
             print("nb %d %s gains (%.1f, %.1f, %.1f): bases/step %.3f (whole batch %.3f)  score err max %.2e rms %.2e  "
                   "GPU decode == oracle decode of GPU scores: %s  label mismatch vs all-oracle %.3e (%d of %d)  "
                   "len diff per chunk: max %d, chunks differing %d of %d"
-                  % (nb, {0: "f16x3", 2: "f16f8"}[prec], ig, lg, bb, (lab_o != 0).mean(), lens.mean() / T, err.max(), np.sqrt((err ** 2).mean()), same_dec,
+                  % (nb, {0: "f16x3", 2: "f16f8", 4: "mixed"}[prec], ig, lg, bb, (lab_o != 0).mean(), lens.mean() / T, err.max(), np.sqrt((err ** 2).mean()), same_dec,
                      (lab_o != lab_g).mean(), int((lab_o != lab_g).sum()), lab_o.size,
                      int(np.abs(olen - glen).max()), int((olen != glen).sum()), npick), flush=True)
 

@@ -14,7 +14,9 @@ LIB_PATH = os.environ.get("XNA_LIBXNACALL", os.path.join(_HERE, "libxnacall.so")
 _lib = None
 
 XB_STAGE_NAMES = ("conv", "lstm_in", "lstm_rec", "linear", "decode")
-XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8, XB_PREC_F16F8_IN1 = 0, 1, 2, 3
+XB_PREC_F16X3, XB_PREC_F16, XB_PREC_F16F8, XB_PREC_F16F8_IN1, XB_PREC_MIXED = 0, 1, 2, 3, 4
+PRECISIONS = {"f16x3": XB_PREC_F16X3, "f16": XB_PREC_F16, "f16f8": XB_PREC_F16F8, "f16f8i": XB_PREC_F16F8_IN1,
+              "mixed": XB_PREC_MIXED}
 
 EXPORTS = [
     "xb_ctx_create", "xb_ctx_destroy", "xb_last_error", "xb_device_count", "xb_load_weights",
@@ -24,9 +26,10 @@ EXPORTS = [
     "xb_submit_chunks", "xb_collect_chunks", "xb_ctc_logz", "xb_ctc_alignments",
     "xb_comm_unique_id", "xb_comm_create", "xb_comm_destroy", "xb_comm_rank", "xb_comm_world", "xb_comm_last_error",
     "xb_gather_called", "xb_comm_fence", "xb_comm_synchronize", "xb_stream_wait_event", "xb_align_accuracy",
-    "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam", "xb_reserve_pairing",
+    "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam", "xb_reserve_pairing", "xb_pairing_active", "xb_debug_layer_output",
 ]
 XB_COMM_ID_BYTES = 128
+XB_PIPELINE_SLOTS = 4          # include/xna_basecaller.h
 
 
 class XbConfig(C.Structure):
@@ -80,6 +83,7 @@ def load():
     lib.xb_basecall_chunks_dev.argtypes = [vp, vp, ip, C.c_char_p, vp, vp]
     lib.xb_synchronize.argtypes = [vp]
     lib.xb_reserve_pairing.argtypes = [vp]
+    lib.xb_pairing_active.argtypes = [vp]
     lib.xb_comm_unique_id.argtypes = [C.c_char_p]
     lib.xb_comm_create.argtypes = [C.POINTER(vp), ip, ip, ip, C.c_char_p]
     lib.xb_comm_destroy.argtypes = [vp]
@@ -107,6 +111,7 @@ def load():
     lib.xb_get_stage_times.argtypes = [vp, vp, vp]
     lib.xb_reset_stage_times.argtypes = [vp]
     lib.xb_geometry.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
+    lib.xb_debug_layer_output.argtypes = [vp, ip, ip, vp, vp]
     _lib = lib
     return lib
 
@@ -178,6 +183,14 @@ class Context:
             a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
             self._check(self.lib.xb_load_weights(self.h, k.encode(), a.ctypes.data, a.size))
         self._check(self.lib.xb_weights_ready(self.h))
+
+    def debug_layer_output(self, which, n):
+        """(hi, second) uint16 arrays (T, n, features) of LSTM layer 3 (which = 0) / 4 (1) after the last encode of n chunks."""
+        F = self.cfg.features
+        hi = np.empty((self.T, n, F), dtype=np.uint16)
+        second = np.empty((self.T, n, F), dtype=np.uint16)
+        self._check(self.lib.xb_debug_layer_output(self.h, int(which), int(n), hi.ctypes.data, second.ctypes.data))
+        return hi, second
 
     # ---- host-buffer operators ---------------------------------------------------------
     def encode(self, signal, expand_blanks=True):
@@ -347,8 +360,13 @@ class Context:
         self._check(self.lib.xb_synchronize(self.h))
 
     def reserve_pairing(self):
-        """Allocate the workspaces for two co-scheduled calls now instead of at the first pairing."""
+        """Opt in to the co-scheduling of two asynchronous calls in flight (xb_reserve_pairing: allocates the workspaces for a
+        pair); returns whether the context pairs calls from now on."""
         self._check(self.lib.xb_reserve_pairing(self.h))
+        return self.pairing_active()
+
+    def pairing_active(self):
+        return bool(self.lib.xb_pairing_active(self.h))
 
     def result_stream(self):
         """hipStream_t (int) producing the outputs of the most recent *_dev call (xb_result_stream)."""

@@ -1,6 +1,7 @@
 """
 `bonito basecaller`-compatible command line (ub-bonito/bonito/cli/basecaller.py:24-196): same positional
-arguments, flags, defaults and stderr lines; FASTQ on stdout, `<stdout-stem>_summary.tsv` beside it.
+arguments, flags, defaults and stderr lines; FASTQ (or, redirected to `*.sam`, unaligned SAM text) on stdout,
+`<stdout-stem>_summary.tsv` beside it.
 
 Differences, all outside the hot path: reads come from `*.xsig.npz` signal bundles (no HDF5/VBZ reader in
 this image, see reads.py); --reference / --modified-bases / --save-ctc are rejected (mappy / remora /
@@ -17,7 +18,7 @@ import numpy as np
 
 from .. import dist as xdist
 from ..io import Writer, biofmt
-from ..reads import get_reads
+from ..reads import get_read_groups, get_reads
 from ..util import column_to_set, init, load_model, load_symbol
 
 
@@ -124,9 +125,15 @@ def main(args):
         exit(1)
     fmt = biofmt(aligned=False)
     sys.stderr.write(f"> outputting {fmt.aligned} {fmt.name}\n")
-    if fmt.name != "fastq":
-        sys.stderr.write("> error: only FASTQ output is implemented (redirect stdout to *.fastq)\n")
+    if fmt.name not in ("fastq", "sam"):
+        sys.stderr.write("> error: FASTQ and SAM text output are implemented (redirect stdout to *.fastq or *.sam); "
+                         "BAM / CRAM need htslib\n")
         exit(1)
+    # SAM: the header carries one @RG line per (run, model) of the selected reads -- metadata only (cli/basecaller.py:100-106)
+    groups = []
+    if fmt.name != "fastq" and rank == 0:
+        groups = get_read_groups(args.reads_directory, args.model_directory, recursive=args.recursive,
+                                 read_ids=column_to_set(args.read_ids), skip=args.skip)
 
     results = basecall(model, reads, reverse=args.revcomp,
                        batchsize=model.config["basecaller"]["batchsize"],
@@ -141,7 +148,7 @@ def main(args):
                 pass
             return
 
-    writer = Writer(fmt.mode, results, aligner=None, group_key=args.model_directory)
+    writer = Writer(fmt.mode, results, aligner=None, group_key=args.model_directory, groups=groups)
     writer.start()
     writer.join()
     if writer.error is not None:

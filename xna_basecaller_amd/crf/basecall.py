@@ -4,6 +4,7 @@ unbatch -> stitch -> strings, as five generator stages on background threads wit
 (bonito/multiprocessing.py:20-24,92-122), strict FIFO order.
 """
 import queue
+from collections import deque
 from threading import Thread
 
 import numpy as np
@@ -90,28 +91,35 @@ def _scores_dict(sequence):
 
 def compute_sequences_pipelined(model, batches, reverse=False):
     """
-    The device stage of `basecall`: (key, batch) stream -> (key, sequence (n,T) int8 left-packed ASCII) with TWO batches
+    The device stage of `basecall`: (key, batch) stream -> (key, sequence (n,T) int8 left-packed ASCII) with several batches
     in flight on the device: batch k+1 is submitted (pinned staging, H2D on a copy stream, fused kernels, D2H) before
-    batch k's result is waited for, so the GPU never idles while the host unpacks results.  Results come out in input
-    order, one batch late.  (compute_scores is the same operator, synchronous, with the reference's full result dict.)
+    batch k's result is waited for, so the GPU never idles while the host unpacks results.  Where the context co-schedules two
+    calls per device pass (Model.pipeline_depth: batches of at most 512 chunks) FOUR batches rotate through four staging
+    slots -- batch k+3 is submitted before batch k is collected, so pair (k+2, k+3) is on the device, its H2D copies done,
+    while the host waits for pair (k, k+1) -- otherwise two.  Results come out in input order, depth - 1 batches late.
+    (compute_scores is the same operator, synchronous, with the reference's full result dict.)
     """
     if reverse or not model.encoder[-1].expand_blanks:
         for key, batch in batches:                       # decode of host-side reverse-complemented scores: synchronous
             yield key, compute_scores(model, batch, reverse=reverse)["sequence"]
         return
-    pending, slot = None, 0
+    pending, slot, depth = deque(), 0, 2
     for key, batch in batches:
         shape = np.asarray(batch).shape
-        if pending is not None and not model.context_is_current(shape[-1], shape[0]):
-            yield pending[0], model.collect_chunks(pending[1])[0]        # drain before the context is rebuilt
-            pending = None
-        handle = model.submit_chunks(slot, batch)
-        slot ^= 1
-        if pending is not None:
-            yield pending[0], model.collect_chunks(pending[1])[0]
-        pending = (key, handle)
-    if pending is not None:
-        yield pending[0], model.collect_chunks(pending[1])[0]
+        if pending and not model.context_is_current(shape[-1], shape[0]):
+            while pending:                                                # drain before the context is rebuilt
+                k, h = pending.popleft()
+                yield k, model.collect_chunks(h)[0]
+        if not pending:
+            depth, slot = model.pipeline_depth(shape[-1], shape[0]), 0
+        pending.append((key, model.submit_chunks(slot, batch)))
+        slot = (slot + 1) % depth
+        if len(pending) == depth:                                         # the slot the next batch goes into
+            k, h = pending.popleft()
+            yield k, model.collect_chunks(h)[0]
+    while pending:
+        k, h = pending.popleft()
+        yield k, model.collect_chunks(h)[0]
 
 
 def compute_scores_pipelined(model, batches, reverse=False):

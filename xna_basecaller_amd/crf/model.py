@@ -282,12 +282,13 @@ class Model(torch.nn.Module):
         self._device = 0
         self._ctx = None
         self._ctx_key = None
-        # f16f8 (default): fp16 product + FP8 block-scaled correction products, |score error| ~4e-5; f16x3: three fp16
-        # products, ~3e-6; f16: one product, ~1e-3..2e-3 (what the reference's model.half() computes); f16f8i: f16f8 with
-        # single-product LSTM input projections, ~6e-4 max, 1.19x faster
-        self.precision = {"f16x3": _lib.XB_PREC_F16X3, "f16": _lib.XB_PREC_F16, "f16f8": _lib.XB_PREC_F16F8,
-                          "f16f8i": _lib.XB_PREC_F16F8_IN1}[
-            os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "f16f8"))]
+        # mixed (default): the feed-forward projections in three fp16 products, the recurrent ones as fp16 product + FP8
+        # block-scaled correction products -- |score error| 3.4e-4 max on trained-like (peaky) weights, 3e-5 on seeded ones;
+        # f16f8: FP8 corrections everywhere, 1.15x faster, 1.1e-3 / 7e-5 (on the north star's 1e-3 tolerance with peaky weights);
+        # f16x3: three fp16 products everywhere, 6e-5 / 6e-6; f16: one product, ~1e-3..2e-3 (what the reference's model.half()
+        # computes); f16f8i: f16f8 with single-product LSTM input projections (seeded weights: ~6e-4 max)
+        self.precision = _lib.PRECISIONS[
+            os.environ.get("XNA_PRECISION", config.get("basecaller", {}).get("precision", "mixed"))]
 
     # ---- torch.nn.Module surface used by load_model -------------------------------------
     def to(self, device=None, *args, **kwargs):
@@ -416,11 +417,24 @@ class Model(torch.nn.Module):
         return self.context(T * self.stride, N).beam_search(scores, self.alphabet, beam_width, beam_cut, scale, offset)
 
     def submit_chunks(self, slot, batch):
-        """Enqueue the fused encode + decode of a (N,1,L) batch in pipeline slot 0/1 without waiting; returns a handle
+        """Enqueue the fused encode + decode of a (N,1,L) batch in pipeline slot 0 .. 3 without waiting; returns a handle
         for collect_chunks.  The caller keeps at most one handle per slot in flight."""
         sig = self._as_signal(batch)
         ctx = self.context(sig.shape[1], sig.shape[0])
         return ctx, slot, ctx.submit_chunks(slot, sig, self.alphabet)
+
+    def pipeline_depth(self, chunk_len, n):
+        """Batches the host pipeline keeps in flight on the context for (chunk_len, n): 4 when the context co-schedules two
+        calls per device pass (pair k+1 is then on the device before the host waits for pair k), else 2.  Opts the context
+        in to the pairing (xb_reserve_pairing) the first time it is asked."""
+        ctx = self.context(chunk_len, n)
+        if not getattr(ctx, "_pairing_asked", False):
+            ctx._pairing_asked = True
+            try:
+                ctx.reserve_pairing()
+            except _lib.XbError:            # no room for a pair (XB_ERR_NOMEM): the context carries on unpaired
+                pass
+        return 4 if ctx.pairing_active() else 2
 
     @staticmethod
     def collect_chunks(handle):

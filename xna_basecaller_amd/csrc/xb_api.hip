@@ -53,7 +53,7 @@ struct xb_ctx {
         hipEvent_t h2d = nullptr, done = nullptr;
         int n = 0;
         bool busy = false;
-    } slots[2];
+    } slots[XB_PIPELINE_SLOTS];
     bool pipeline_failed = false;          // a collected batch reported a lost rendezvous: every batch in flight fails with it
     hipStream_t stream_copy = nullptr;     // H2D of the next batch beside the compute of the current one
     std::vector<hipEvent_t> deps;    // timing-less events for the cross-stream dependencies (reused every call)
@@ -113,16 +113,23 @@ struct xb_ctx {
     unsigned *sync = nullptr;    // [64 groups * 32] counters + error word at the end
     unsigned *error = nullptr;
     int lstm_mode = 0;
-    int lstm_resident = -1;      // workgroups of the persistent kernel admitted per CU (occupancy query, lazily)
-    int lstm_dual_resident = -1; // the same for the two-groups-per-workgroup variant (larger LDS footprint)
+    // workgroups of the persistent kernel admitted per CU, by recurrence arithmetic (nsplit 1..5) and one / two groups per
+    // workgroup (occupancy query, lazily; -1 = not asked yet)
+    int lstm_resident[6][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
+    // Arithmetic of every contraction stage (GemmParams::nsplit: 1 fp16 product, 2 + FP8 corrections, 3 three fp16 products):
+    // conv3, the five input projections, the five recurrences, the CRF linear layer.  One value everywhere for the plain
+    // precisions; XB_PREC_MIXED (and the diagnostic XB_X3_STAGES mask) mix 2 and 3.  An activation tensor's second part
+    // (q8 image or fp16 residual) follows the stage that CONSUMES it.
+    int ns_conv = 3, ns_in[5] = {3, 3, 3, 3, 3}, ns_rec[5] = {3, 3, 3, 3, 3}, ns_lin = 3;
     int in1_layers = 31;         // XB_IN1_LAYERS (diagnostic): layers whose input projection XB_PREC_F16F8_IN1 reduces
     int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
-    // Two asynchronous basecalls in flight are co-scheduled (XB_FUSE, default on for contexts of at most 512 chunks): the first
-    // xb_basecall_chunks_dev of a pair is held back until the second arrives, then both batches go through the encoder and the
-    // decode as ONE batch (the recurrence then runs two chunk groups per workgroup).  Every other entry point,
-    // xb_synchronize and xb_result_stream first launch a held-back call on its own.
+    // Two asynchronous basecalls in flight are co-scheduled once the caller has opted in with xb_reserve_pairing (contexts of at
+    // most 512 chunks; XB_FUSE=0 refuses): the first xb_basecall_chunks_dev of a pair is held back until the second arrives, then
+    // both batches go through the encoder and the decode as ONE batch (the recurrence then runs two chunk groups per workgroup,
+    // DESIGN.md 4.1 / 4.5).  Every other entry point, xb_synchronize and xb_result_stream first launch a held-back call on its own.
+    // Without the opt-in every asynchronous call is enqueued before it returns.
     struct Call {
         const float *signal = nullptr;
         int n = 0;
@@ -133,7 +140,8 @@ struct xb_ctx {
         void (*after)(void *) = nullptr;        // xb_comm: the gather of this call's results, enqueued right behind it
         void *after_arg = nullptr;
     };
-    int fuse = 1;
+    int fuse_ok = 1;                            // pairing is possible in this context (schedule, batch size, XB_FUSE)
+    int fuse = 0;                               // ... and the caller asked for it (xb_reserve_pairing)
     int cap = 0;                                // chunks the workspaces hold (2 * max_batch when fusing is possible)
     Call held;
     bool holding = false, flushing = false;
@@ -220,7 +228,7 @@ int alloc_workspaces(xb_ctx *ctx, int cap)
     rc = rc ? rc : dev_alloc(ctx, &ctx->labels, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq, N * T);
     rc = rc ? rc : dev_alloc(ctx, &ctx->seq_len, N);
-    if (ctx->fuse) {         // results of a pair before they are split (two short calls can pair inside max_batch chunks)
+    if (ctx->fuse_ok) {      // results of a pair before they are split (two short calls can pair inside max_batch chunks)
         rc = rc ? rc : dev_alloc(ctx, &ctx->fseq, N * T);
         rc = rc ? rc : dev_alloc(ctx, &ctx->flen, N);
     }
@@ -387,6 +395,7 @@ int check_ready(xb_ctx *ctx, int n)
     if (!ctx) return XB_ERR_INVALID;
     if (!ctx->weights_ready) return fail(ctx, XB_ERR_STATE, "weights not loaded: call xb_load_weights for all 28 tensors, then xb_weights_ready");
     if (n < 1 || n > ctx->cfg.max_batch) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, max_batch=%d]", n, ctx->cfg.max_batch);
+    if (ctx->cap < ctx->cfg.max_batch) return fail(ctx, XB_ERR_NOMEM, "the context lost its workspaces (a reallocation failed)");
     return XB_OK;
 }
 
@@ -404,11 +413,29 @@ int check_device_error(xb_ctx *ctx)
 }
 
 // ---- encoder orchestration --------------------------------------------------------------
-int precision_nsplit(const xb_ctx *ctx)
+int precision_nsplit(int pr)
 {
-    const int pr = ctx->cfg.precision;
-    return pr == XB_PREC_F16 ? 1 : ((pr == XB_PREC_F16F8 || pr == XB_PREC_F16F8_IN1) ? 2 : 3);
+    return pr == XB_PREC_F16 ? 1 : ((pr == XB_PREC_F16F8 || pr == XB_PREC_F16F8_IN1 || pr == XB_PREC_MIXED) ? 2 : 3);
 }
+
+// Stage mask of the three-product arithmetic inside an f16f8 context: bits 0-4 = input projection of LSTM layer l, bits 5-9 =
+// recurrence of layer l, bit 10 = CRF linear layer, bit 11 = conv3.  XB_PREC_MIXED: every feed-forward projection.  Measured on the
+// peaky model (profiles/r04_x3_attribution.txt): the error variance of plain f16f8 splits as input projections 65 %,
+// linear 18 %, recurrences 13 %, conv3 5 %; per ms of step time the recurrences buy the least, and they are the critical path.
+constexpr int X3_MIXED_STAGES = 0x1f | (1 << 10) | (1 << 11);
+void set_stage_arithmetic(xb_ctx *ctx, int x3_mask)
+{
+    const int base = precision_nsplit(ctx->cfg.precision);
+    const bool mix = base == 2;
+    for (int l = 0; l < 5; ++l) {
+        ctx->ns_in[l] = mix && ((x3_mask >> l) & 1) ? 3 : base;
+        ctx->ns_rec[l] = mix && ((x3_mask >> (5 + l)) & 1) ? 3 : base;
+    }
+    ctx->ns_lin = mix && ((x3_mask >> 10) & 1) ? 3 : base;
+    ctx->ns_conv = mix && ((x3_mask >> 11) & 1) ? 3 : base;
+}
+// second part an activation tensor needs for a consumer of arithmetic ns: 2 = q8 image, 1 = fp16 residual, 0 = none read
+int second_part(int ns) { return ns == 2 ? 2 : (ns == 3 ? 1 : 0); }
 
 // the GEMM that consumes a layer's output rows of time steps [ta, tb): the input projection of LSTM layer `layer`
 // (layer < 5, into `gin_out`) or the CRF linear layer (layer == 5, into the scores)
@@ -426,7 +453,7 @@ int launch_row_gemm(xb_ctx *ctx, const NextGemm &ng, int n, int ta, int tb, hipS
     xb::GemmParams g{};
     const size_t r0 = (size_t)ta * n;
     g.a_hi = ng.x_hi + r0 * F; g.a_lo = ng.x_lo + r0 * F;
-    g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = precision_nsplit(ctx);
+    g.M = (tb - ta) * n; g.K = F; g.lda = F; g.ldb = F; g.nsplit = ng.layer < 5 ? ctx->ns_in[ng.layer] : ctx->ns_lin;
     g.ldc = ng.ldc; g.out_f32 = ng.out + r0 * ng.ldc;
     g.one_per_cu = shadow && ctx->gemm_shadow_wgs == 1;
     g.sn = ctx->gemm_sn;
@@ -485,11 +512,15 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     // group, 32 CUs per XCD) allows one group per XCD = 8 groups = 512 chunks per launch
     // ... and the occupancy calculator has to admit at least one such workgroup per CU (queried once per context); a
     // context that cannot keep the persistent kernel resident falls back to one launch per time step
-    const int rec_nsplit = (ctx->lstm_i8 && ctx->whh_q1[layer]) ? (ctx->lstm_i8 == 2 ? 5 : 4) : precision_nsplit(ctx);
-    if (ctx->lstm_resident < 0) ctx->lstm_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 0);
-    if (ctx->lstm_dual_resident < 0) ctx->lstm_dual_resident = xb::lstm_resident_per_cu(F, rec_nsplit, 1);
-    const bool dual_ok = ctx->lstm_dual != 0 && ctx->lstm_dual_resident >= 1;
-    const int gmax = ctx->lstm_resident >= 1 ? 8 * ((ctx->cu_count / 8) / members) : 0;
+    // what the GEMM that reads this layer's output needs as the second part; the int8-limb recurrence writes hi + q8 only
+    const int y_need = second_part(layer < 4 ? ctx->ns_in[layer + 1] : ctx->ns_lin);
+    const bool i8 = ctx->lstm_i8 && ctx->whh_q1[layer] && ctx->ns_rec[layer] == 2 && y_need != 1;
+    const int rec_nsplit = i8 ? (ctx->lstm_i8 == 2 ? 5 : 4) : ctx->ns_rec[layer];
+    int (&res)[2] = ctx->lstm_resident[rec_nsplit];
+    if (res[0] < 0) res[0] = xb::lstm_resident_per_cu(F, rec_nsplit, 0);
+    if (res[1] < 0) res[1] = xb::lstm_resident_per_cu(F, rec_nsplit, 1);
+    const bool dual_ok = ctx->lstm_dual != 0 && res[1] >= 1;
+    const int gmax = res[0] >= 1 ? 8 * ((ctx->cu_count / 8) / members) : 0;
     if (mode == 0) mode = gmax >= 1 ? 2 : 1;
     if (mode == 2 && gmax < 1) return fail(ctx, XB_ERR_INVALID, "persistent LSTM needs %d co-resident workgroups, device has %d CUs", members, ctx->cu_count);
     XB_HIP(ctx, hipMemsetAsync(ctx->c_state, 0, sizeof(float) * (size_t)n * F, ctx->stream));
@@ -497,8 +528,9 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     p.gin = gin; p.w_hi = ctx->whh_hi[layer]; p.w_lo = ctx->whh_lo[layer];
     p.y_hi = xout_hi; p.y_lo = xout_lo; p.c_state = ctx->c_state; p.xh = ctx->xh;
     p.T = T; p.N = n; p.F = F; p.reverse = (layer % 2) == 0;
-    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = precision_nsplit(ctx); p.w_exp = ctx->whh_exp[layer];
-    if (ctx->lstm_i8 && ctx->whh_q1[layer]) {
+    p.sync = ctx->sync; p.error = ctx->error; p.nsplit = ctx->ns_rec[layer]; p.w_exp = ctx->whh_exp[layer];
+    p.y_alt = (p.nsplit == 2 || p.nsplit == 3) && y_need != 0 && y_need != second_part(p.nsplit);
+    if (i8) {
         p.nsplit = ctx->lstm_i8 == 2 ? 5 : 4; p.wq1 = ctx->whh_q1[layer]; p.wq0 = ctx->whh_q0[layer]; p.wscale = ctx->whh_sc[layer];
     }
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
@@ -617,7 +649,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
 {
     const xb_config &c = ctx->cfg;
     const int F = c.features, T = ctx->T;
-    const int nsplit = precision_nsplit(ctx);
+    const int nsplit = ctx->ns_conv;
     ctx->dep_next = 0;
     {
         StageScope sc(ctx, XB_STAGE_CONV, 2);
@@ -631,6 +663,7 @@ int run_encoder(xb_ctx *ctx, const float *d_signal, int n, int expand, float *sc
         g.M = T * n; g.Nn = F; g.K = ctx->kp; g.lda = ctx->kp; g.ldb = ctx->kp;
         g.bias = ctx->b3; g.out_hi = ctx->x_hi[0]; g.out_lo = ctx->x_lo[0]; g.ldc = F; g.nsplit = nsplit;
         g.a_exp = 0; g.b_exp = ctx->w3_exp; g.out_exp = 0;
+        g.out_fmt = second_part(ctx->ns_in[0]);            // (0: hi only is read -- the GEMM's own form)
         if (ctx->gemm4) { g.b4 = ctx->w3_f4; g.b4_kstride = ctx->w3_ks; }
         XB_HIP(ctx, xb::launch_gemm(g, xb::EPI_SILU_SPLIT, ctx->stream));
     }
@@ -744,7 +777,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (cfg->winlen < 1 || cfg->winlen > 31 || cfg->winlen % 2 == 0 || cfg->stride < 1 || cfg->stride > 8)
         return fail(nullptr, XB_ERR_INVALID, "winlen %d / stride %d unsupported", cfg->winlen, cfg->stride);
     if (cfg->chunk_len < cfg->stride || cfg->max_batch < 1) return fail(nullptr, XB_ERR_INVALID, "bad chunk_len/max_batch");
-    if (cfg->precision < XB_PREC_F16X3 || cfg->precision > XB_PREC_F16F8_IN1) return fail(nullptr, XB_ERR_INVALID, "bad precision");
+    if (cfg->precision < XB_PREC_F16X3 || cfg->precision > XB_PREC_MIXED) return fail(nullptr, XB_ERR_INVALID, "bad precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, XB_ERR_NO_GPU, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(nullptr, XB_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
@@ -761,6 +794,11 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     ctx->kp = (16 * cfg->winlen + 31) & ~31;
     ctx->ld_nb = (ctx->O + 3) & ~3;
     ctx->lstm_mode = cfg->lstm_mode;
+    {
+        int x3 = cfg->precision == XB_PREC_MIXED ? X3_MIXED_STAGES : 0;
+        if (const char *e = getenv("XB_X3_STAGES")) x3 = (int)strtol(e, nullptr, 0) & 0xfff;      // diagnostic (tools/x3_stages.py)
+        set_stage_arithmetic(ctx, x3);
+    }
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
     if (const char *e = getenv("XB_LSTM_LOCAL")) ctx->lstm_local = atoi(e) != 0;
@@ -801,7 +839,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
         if (const char *e = getenv("XB_TIME_SLABS")) ctx->time_slabs = atoi(e) > 0 ? atoi(e) : 1;
         if (const char *e = getenv("XB_SLAB_STEPS")) ctx->slab_steps = atoi(e) >= 8 ? atoi(e) : 0;
         if (const char *e = getenv("XB_LSTM_SIGNAL")) ctx->lstm_signal = atoi(e) < 0 || atoi(e) > 2 ? 2 : atoi(e);
-        if (const char *e = getenv("XB_FUSE")) ctx->fuse = atoi(e) != 0;
+        if (const char *e = getenv("XB_FUSE")) ctx->fuse_ok = atoi(e) != 0;
         // rocprofv3 counter collection (--pmc) runs one kernel at a time; hipStreamWaitValue32 is a spinning kernel
         // (__amd_rocclr_streamOpsWait) there, which would wait for a flag the serialised recurrence can never raise: slab launches
         {
@@ -811,7 +849,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     }
 
     // co-scheduling two calls: only where the pair fits one launch of two groups per workgroup
-    if (!(ctx->fuse && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= 512)) ctx->fuse = 0;
+    if (!(ctx->fuse_ok && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= 512)) ctx->fuse_ok = 0;
     const size_t F = cfg->features;
     int rc = alloc_workspaces(ctx, cfg->max_batch);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
@@ -851,8 +889,11 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
 XB_API void xb_ctx_destroy(xb_ctx *ctx)
 {
     if (!ctx) return;
-    ctx->holding = false;       // a call nobody waited for
     (void)hipSetDevice(ctx->device);
+    // a call nobody waited for: launch it all the same -- its deferred gather (xb_gather_called) is a collective the other ranks
+    // enter too, and the streams are drained below before anything is freed
+    if (ctx->holding && ctx->weights_ready && ctx->cap > 0) (void)flush_held(ctx);
+    ctx->holding = false;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
@@ -883,6 +924,11 @@ XB_API int xb_load_weights(xb_ctx *ctx, const char *name, const float *host, int
     const int64_t want = expected_size(ctx, name);
     if (want < 0) return fail(ctx, XB_ERR_INVALID, "unknown state-dict key '%s'", name);
     if (want != n) return fail(ctx, XB_ERR_INVALID, "'%s': got %lld elements, config implies %lld", name, (long long)n, (long long)want);
+    // a held-back basecall belongs to the weights it was called with (loading clears weights_ready, the launch needs it)
+    if (ctx->holding) {
+        XB_HIP(ctx, hipSetDevice(ctx->device));
+        if (int rc = flush_held(ctx)) return rc;
+    }
     ctx->host_w[name].assign(host, host + n);
     ctx->weights_ready = false;
     return XB_OK;
@@ -892,6 +938,7 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
 {
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcf = flush_held(ctx)) return rcf;          // with the weights it was called with
     const int F = ctx->cfg.features, W = ctx->cfg.winlen;
     auto need = [&](const std::string &k) -> const std::vector<float> * {
         auto it = ctx->host_w.find(k);
@@ -919,13 +966,12 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
     if ((rc = upload(ctx, &ctx->b2, *need("encoder.1.conv.bias")))) return rc;
     if ((rc = upload(ctx, &ctx->b3, *need("encoder.2.conv.bias")))) return rc;
     std::vector<half_t> hi, lo;
-    const bool q8 = ctx->cfg.precision == XB_PREC_F16F8 || ctx->cfg.precision == XB_PREC_F16F8_IN1;
-    split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo, q8 ? &ctx->w3_exp : nullptr);
+    // every weight tensor in the form its stage's arithmetic reads (q8 image for nsplit 2, fp16 residual for 3)
+    split_rows(need("encoder.2.conv.weight")->data(), F, 16 * W, ctx->kp, hi, lo, ctx->ns_conv == 2 ? &ctx->w3_exp : nullptr);
     if ((rc = upload(ctx, &ctx->w3_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->w3_lo, lo))) return rc;
-    const int ns = precision_nsplit(ctx);
     std::vector<unsigned char> f4;
-    fragment_major(hi, lo, F, ctx->kp, ctx->kp, ns, f4, &ctx->w3_ks);
+    fragment_major(hi, lo, F, ctx->kp, ctx->kp, ctx->ns_conv, f4, &ctx->w3_ks);
     if ((rc = upload(ctx, &ctx->w3_f4, f4))) return rc;
     for (int l = 0; l < 5; ++l) {
         const std::string pre = "encoder." + std::to_string(4 + l) + ".rnn.";
@@ -939,19 +985,20 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
                 memcpy(&wh[((size_t)u * 4 + q) * F], &whh[((size_t)q * F + u) * F], sizeof(float) * F);
                 bb[(size_t)u * 4 + q] = bih[(size_t)q * F + u] + bhh[(size_t)q * F + u];
             }
-        split_rows(wi.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->wih_exp[l] : nullptr);
+        split_rows(wi.data(), 4 * F, F, F, hi, lo, ctx->ns_in[l] == 2 ? &ctx->wih_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->wih_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->wih_lo[l], lo))) return rc;
-        fragment_major(hi, lo, 4 * F, F, F, ns, f4, &ctx->wih_ks);
+        fragment_major(hi, lo, 4 * F, F, F, ctx->ns_in[l], f4, &ctx->wih_ks);       // (the k-tile stride is the same for nsplit 2 and 3)
         if ((rc = upload(ctx, &ctx->wih_f4[l], f4))) return rc;
         if (ctx->cfg.precision == XB_PREC_F16F8_IN1) {
             fragment_major(hi, lo, 4 * F, F, F, 1, f4, &ctx->wih_ksh);
             if ((rc = upload(ctx, &ctx->wih_f4h[l], f4))) return rc;
         }
-        split_rows(wh.data(), 4 * F, F, F, hi, lo, q8 ? &ctx->whh_exp[l] : nullptr);
+        split_rows(wh.data(), 4 * F, F, F, hi, lo, ctx->ns_rec[l] == 2 ? &ctx->whh_exp[l] : nullptr);
         if ((rc = upload(ctx, &ctx->whh_hi[l], hi))) return rc;
         if ((rc = upload(ctx, &ctx->whh_lo[l], lo))) return rc;
-        if (ctx->lstm_i8 && q8 && (F == 64 || F % 128 == 0)) {
+        ctx->whh_q1[l] = nullptr;
+        if (ctx->lstm_i8 && ctx->ns_rec[l] == 2 && (F == 64 || F % 128 == 0)) {
             // int8-limb image: per row q = round(W / s * 32512), s = max |W| of the row; q = 256 d1 + d0 with both digits in
             // [-128, 127]; h is published as round(h * 32512) the same way, so W h = s / 32512^2 * sum q_w q_h
             std::vector<int8_t> d1((size_t)4 * F * F), d0((size_t)4 * F * F);
@@ -974,10 +1021,10 @@ XB_API int xb_weights_ready(xb_ctx *ctx)
         }
         if ((rc = upload(ctx, &ctx->lbias[l], bb))) return rc;
     }
-    split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo, q8 ? &ctx->wl_exp : nullptr);
+    split_rows(need("encoder.9.linear.weight")->data(), ctx->O, F, F, hi, lo, ctx->ns_lin == 2 ? &ctx->wl_exp : nullptr);
     if ((rc = upload(ctx, &ctx->wl_hi, hi))) return rc;
     if ((rc = upload(ctx, &ctx->wl_lo, lo))) return rc;
-    fragment_major(hi, lo, ctx->O, F, F, ns, f4, &ctx->wl_ks);
+    fragment_major(hi, lo, ctx->O, F, F, ctx->ns_lin, f4, &ctx->wl_ks);
     if ((rc = upload(ctx, &ctx->wl_f4, f4))) return rc;
     if ((rc = upload(ctx, &ctx->bl, *need("encoder.9.linear.bias")))) return rc;
     ctx->host_w.clear();
@@ -1360,14 +1407,15 @@ XB_API int xb_basecall_chunks_beam(xb_ctx *ctx, const float *signal, int n, cons
 // room for two co-scheduled calls (once per context; everything in flight is waited for, no held call exists here)
 static int reserve_pairing(xb_ctx *ctx)
 {
-    if (!ctx->fuse) return XB_ERR_STATE;
+    if (!ctx->fuse_ok) return XB_ERR_STATE;
     if (ctx->cap >= 2 * ctx->cfg.max_batch) return XB_OK;
     int rc = sync_all(ctx);
     if (rc) return rc;
     rc = alloc_workspaces(ctx, 2 * ctx->cfg.max_batch);
     if (rc) {                                           // out of memory: back to one call per pass for good
-        ctx->fuse = 0;
+        ctx->fuse = ctx->fuse_ok = 0;
         const int rc2 = alloc_workspaces(ctx, ctx->cfg.max_batch);
+        // (should even that fail the context has no workspaces left: cap == 0, and check_ready refuses every call)
         return rc2 ? rc2 : rc;
     }
     return XB_OK;
@@ -1378,9 +1426,13 @@ XB_API int xb_reserve_pairing(xb_ctx *ctx)
     if (!ctx) return XB_ERR_INVALID;
     XB_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = flush_held(ctx)) return rc;
-    if (!ctx->fuse) return XB_OK;                       // nothing to reserve: every call runs on its own
-    return reserve_pairing(ctx);
+    if (!ctx->fuse_ok) return XB_OK;                    // this context does not pair calls: every call runs on its own
+    const int rc = reserve_pairing(ctx);
+    if (rc == XB_OK) ctx->fuse = 1;                     // from now on an asynchronous basecall may be held back for its partner
+    return rc;                                          // (XB_ERR_NOMEM: no room for a pair; the context carries on unpaired)
 }
+
+XB_API int xb_pairing_active(const xb_ctx *ctx) { return ctx && ctx->fuse ? 1 : 0; }
 
 // what follows a call's decode on its result stream: the host pipeline's D2H copies and done event, a deferred gather
 static int call_post_actions(xb_ctx *ctx, const xb_ctx::Call &c, hipStream_t rs)
@@ -1546,7 +1598,7 @@ XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, c
 {
     int rc = check_ready(ctx, n);
     if (rc) return rc;
-    if (slot < 0 || slot > 1 || !signal || !alphabet) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
+    if (slot < 0 || slot >= XB_PIPELINE_SLOTS || !signal || !alphabet) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
     XB_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = ensure_slot(ctx, slot))) return rc;
     xb_ctx::Slot &sl = ctx->slots[slot];
@@ -1573,7 +1625,7 @@ XB_API int xb_submit_chunks(xb_ctx *ctx, int slot, const float *signal, int n, c
 XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_len)
 {
     if (!ctx) return XB_ERR_INVALID;
-    if (slot < 0 || slot > 1 || !seq) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
+    if (slot < 0 || slot >= XB_PIPELINE_SLOTS || !seq) return fail(ctx, XB_ERR_INVALID, "bad slot / null argument");
     xb_ctx::Slot &sl = ctx->slots[slot];
     if (!sl.busy) return fail(ctx, XB_ERR_STATE, "slot %d has nothing in flight", slot);
     XB_HIP(ctx, hipSetDevice(ctx->device));
@@ -1587,7 +1639,9 @@ XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_le
     // on a device in an unknown state) -- and is reset once the pipeline has drained.
     if (*sl.h_err != 0) ctx->pipeline_failed = true;
     if (ctx->pipeline_failed) {
-        if (!ctx->slots[0].busy && !ctx->slots[1].busy) {
+        bool any_busy = false;
+        for (auto &s2 : ctx->slots) any_busy = any_busy || s2.busy;
+        if (!any_busy) {
             (void)sync_all(ctx);
             (void)hipMemset(ctx->error, 0, sizeof(unsigned));
             ctx->pipeline_failed = false;
@@ -1600,6 +1654,8 @@ XB_API int xb_collect_chunks(xb_ctx *ctx, int slot, int8_t *seq, int32_t *seq_le
 XB_API int xb_set_profiling(xb_ctx *ctx, int on)
 {
     if (!ctx) return XB_ERR_INVALID;
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_held(ctx)) return rc;            // a held-back call is timed (or not) as it was when it was made
     ctx->profiling = on != 0;
     return XB_OK;
 }
@@ -1635,6 +1691,22 @@ XB_API int xb_geometry(const xb_ctx *ctx, int *T, int *S, int *C_blank, int *C_n
     if (S) *S = ctx->S;
     if (C_blank) *C_blank = ctx->S * (ctx->cfg.n_base + 1);
     if (C_noblank) *C_noblank = ctx->O;
+    return XB_OK;
+}
+
+// Diagnostic (tests of the mixed-precision encoder): the activation tensors the last xb_encode / xb_encode_dev of `n` chunks left
+// in the ping-pong buffers -- which = 0: output of LSTM layer 3, 1: output of LSTM layer 4 -- as (T, n, features) fp16 bit
+// patterns `hi` and the raw 2-byte-per-element second part (fp16 residual or q8 image, whichever the consuming stage reads).
+XB_API int xb_debug_layer_output(xb_ctx *ctx, int which, int n, uint16_t *hi, uint16_t *second)
+{
+    if (!ctx || !hi || !second || which < 0 || which > 1) return XB_ERR_INVALID;
+    if (n < 1 || n > ctx->cap) return fail(ctx, XB_ERR_INVALID, "batch %d outside [1, %d]", n, ctx->cap);
+    XB_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = join_async_decode(ctx)) return rc;
+    if (int rc = sync_all(ctx)) return rc;
+    const size_t bytes = sizeof(uint16_t) * (size_t)ctx->T * n * ctx->cfg.features;
+    XB_HIP(ctx, hipMemcpy(hi, ctx->x_hi[which], bytes, hipMemcpyDeviceToHost));
+    XB_HIP(ctx, hipMemcpy(second, ctx->x_lo[which], bytes, hipMemcpyDeviceToHost));
     return XB_OK;
 }
 

@@ -74,7 +74,10 @@ struct xb_comm {
     hipEvent_t ready = nullptr, done[2] = {};       // producer -> gather; gather -> producer (the last two gathers)
     unsigned issued = 0;          // gathers enqueued on the stream so far
     unsigned queued = 0;          // gathers asked for so far (a gather can wait for a held-back basecall: xb_gather_called)
-    int deferred_rc = 0;          // failure of a deferred gather, reported by the next call
+    int failed_rc = 0;            // a collective of this communicator failed (or could not be enqueued): STICKY.  The other ranks
+                                  // have entered, or will enter, that all-gather; skipping it here and carrying on would leave
+                                  // them blocked in it.  Every later gather / fence / synchronize fails with this code and the
+                                  // caller has to abort all ranks (no collective of a failed communicator can be trusted).
     std::string err;
 };
 
@@ -158,7 +161,7 @@ void gather_later(void *p)
 {
     GatherArgs *g = static_cast<GatherArgs *>(p);
     const int rc = gather_now(g->c, g->ctx, g->d_seq, g->d_len, g->n, g->T, g->all_seq, g->all_len);
-    if (rc != XB_OK) g->c->deferred_rc = rc;        // reported by the next xb_gather_called / xb_comm_synchronize
+    (void)rc;                                       // a failure is sticky in the communicator: the next call reports it
     delete g;
 }
 }  // namespace
@@ -168,7 +171,7 @@ XB_API int xb_gather_called(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const 
 {
     if (!c) return XB_ERR_INVALID;
     if (!d_seq || !d_seq_len || !d_all_seq || !d_all_len || n < 1 || T < 1) return cfail(c, XB_ERR_INVALID, "bad argument");
-    if (c->deferred_rc != XB_OK) { const int rc = c->deferred_rc; c->deferred_rc = XB_OK; return rc; }
+    if (c->failed_rc != XB_OK) return c->failed_rc;           // xb_comm_last_error holds the first failure
     if (ctx) {
         // the basecall that writes d_seq may be held back to share a pass with the next one (xb_basecall_chunks_dev): the gather
         // is then enqueued right behind its launch, in the order of the xb_gather_called calls
@@ -185,20 +188,24 @@ namespace {
 int gather_now(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_seq_len, int n, int T, int8_t *d_all_seq,
                int32_t *d_all_len)
 {
-    if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
+    if (c->failed_rc != XB_OK) return c->failed_rc;
+    // any failure from here on poisons the communicator (failed_rc): this rank's collective sequence no longer matches the others'
+    auto poison = [c](int code, const std::string &msg) { c->failed_rc = code; return cfail(c, code, msg); };
+    if (hipSetDevice(c->device) != hipSuccess) return poison(XB_ERR_HIP, "hipSetDevice failed");
     // order the gather behind the stream that produces (d_seq, d_seq_len); without a context the caller has synchronised
     if (ctx) {
         hipStream_t rs = static_cast<hipStream_t>(xb_result_stream(ctx));
         if (hipEventRecord(c->ready, rs) != hipSuccess || hipStreamWaitEvent(c->stream, c->ready, 0) != hipSuccess)
-            return cfail(c, XB_ERR_HIP, "event hand-off to the gather stream failed");
+            return poison(XB_ERR_HIP, "event hand-off to the gather stream failed");
     }
     int rc = g_rccl.GroupStart();
-    if (rc == NCCL_SUCCESS) rc = g_rccl.AllGather(d_seq_len, d_all_len, (size_t)n, NCCL_INT32, c->comm, c->stream);
+    if (rc != NCCL_SUCCESS) return poison(XB_ERR_DEVICE, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc));
+    rc = g_rccl.AllGather(d_seq_len, d_all_len, (size_t)n, NCCL_INT32, c->comm, c->stream);
     if (rc == NCCL_SUCCESS) rc = g_rccl.AllGather(d_seq, d_all_seq, (size_t)n * T, NCCL_INT8, c->comm, c->stream);
-    const int rc2 = g_rccl.GroupEnd();
+    const int rc2 = g_rccl.GroupEnd();              // only after a successful GroupStart
     if (rc == NCCL_SUCCESS) rc = rc2;
-    if (rc != NCCL_SUCCESS) return cfail(c, XB_ERR_DEVICE, std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc));
-    if (hipEventRecord(c->done[c->issued & 1], c->stream) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipEventRecord failed");
+    if (rc != NCCL_SUCCESS) return poison(XB_ERR_DEVICE, std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc));
+    if (hipEventRecord(c->done[c->issued & 1], c->stream) != hipSuccess) return poison(XB_ERR_HIP, "hipEventRecord failed");
     c->issued += 1;
     return XB_OK;
 }
@@ -207,11 +214,13 @@ int gather_now(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_se
 XB_API int xb_comm_fence(xb_comm *c, xb_ctx *ctx, int lag)
 {
     if (!c || !ctx || lag < 0 || lag > 1) return XB_ERR_INVALID;
+    if (c->failed_rc != XB_OK) return c->failed_rc;
     if (c->queued <= (unsigned)lag) return XB_OK;           // nothing that old has been asked for
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
     // the gathers run in order on one stream: waiting for gather (latest - lag) covers every earlier one
     const unsigned target = c->queued - 1 - (unsigned)lag;
     if (target >= c->issued) (void)xb_result_stream(ctx);  // it still waits for a held-back basecall: launch that now
+    if (c->failed_rc != XB_OK) return c->failed_rc;         // ... whose gather may just have failed
     if (target >= c->issued || c->issued - target > 2) return cfail(c, XB_ERR_STATE, "fence: that gather's event is gone");
     hipEvent_t ev = c->done[target & 1];
     return xb_stream_wait_event(ctx, ev) == XB_OK ? XB_OK : cfail(c, XB_ERR_HIP, "stream wait failed");
@@ -222,8 +231,7 @@ XB_API int xb_comm_synchronize(xb_comm *c)
     if (!c) return XB_ERR_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
     if (hipStreamSynchronize(c->stream) != hipSuccess) return cfail(c, XB_ERR_HIP, "gather stream failed");
-    if (c->deferred_rc != XB_OK) { const int rc = c->deferred_rc; c->deferred_rc = XB_OK; return rc; }
-    return XB_OK;
+    return c->failed_rc;            // XB_OK, or the sticky failure of an earlier (possibly deferred) gather
 }
 
 }  // extern "C"

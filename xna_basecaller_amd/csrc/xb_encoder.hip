@@ -225,6 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
         bj[j] = (p.bias && n < p.Nn) ? p.bias[n] : 0.0f;
     }
     const bool interior = mw + 128 <= p.M && nw + 64 <= p.Nn;
+    // EPI_SILU_SPLIT: the second part of the output follows the arithmetic of the GEMM that CONSUMES it (out_fmt), which in a
+    // mixed-precision encoder need not be this GEMM's own
+    const bool out_q8 = p.out_fmt ? p.out_fmt == 2 : p.nsplit == 2;
     if (EPI == xb::EPI_BIAS_F32 && interior && (p.gin_n == 0 || p.gin_n >= 43)) {
         // interior wave tile: no bounds checks; wave-uniform row bases + one 32-bit lane offset.  Member-major gin
         // (xb_internal.h): row m = t * n + chunk lives at ((t * MB + member) * n + chunk) * 128; the wave's 64 columns lie
@@ -301,7 +304,7 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float v = silu(acc[i][j][r] + bj[j]);
-                    if (p.nsplit == 2) {
+                    if (out_q8) {
                         half_t hi;
                         unsigned char h8, l8;
                         q8_bytes(v, p.out_exp, hi, h8, l8);
@@ -336,7 +339,7 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
                 if (EPI == xb::EPI_BIAS_F32) {
                     p.out_f32[p.gin_n ? xb::gin_offset((size_t)m, n, p.gin_n, p.Nn) : (size_t)m * p.ldc + n] = v;
                 } else if (EPI == xb::EPI_SILU_SPLIT) {
-                    if (p.nsplit == 2) {
+                    if (out_q8) {
                         half_t hi;
                         unsigned char h8, l8;
                         q8_bytes(silu(v), p.out_exp, hi, h8, l8);
@@ -958,9 +961,15 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
 #else
 #define XB_SIG(x) (x)
 #endif
-template <int KS, int NSPLIT, bool DUAL>
+// YALT = true (NSPLIT 2 or 3 only): the layer output y carries the OTHER second part than the exchange image -- the fp16
+// residual when the recurrence itself runs on q8 images (NSPLIT 2), the q8 image when it runs on residuals (NSPLIT 3) -- because
+// the GEMM that consumes y runs in the other arithmetic (mixed-precision encoders: xb_api.hip stage_nsplit).  The extra
+// staging rows live in piece buffer 1, which is idle between the last piece's closing barrier and the next group-step's
+// piece-1 requests.
+template <int KS, int NSPLIT, bool DUAL, bool YALT = false>
 __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 {
+    static_assert(!YALT || NSPLIT == 2 || NSPLIT == 3, "an alternative y image exists for the q8 and the residual arithmetic only");
     constexpr int F = KS * 16;
     constexpr int KP = F < 128 ? F : 128;       // columns per piece
     constexpr int NP = F / KP;                  // pieces per step
@@ -985,6 +994,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
     // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
     unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
+    unsigned *sTy = reinterpret_cast<unsigned *>(smem_raw + NPARTS * PIECE_BYTES);   // YALT: [16][ST_LD] in piece buffer 1
+    static_assert(!YALT || NPARTS * PIECE_BYTES >= 16 * ST_LD * 4, "piece buffer 1 holds the alternative y staging");
     float *sC0 = reinterpret_cast<float *>(sT + STP * 16 * ST_LD);                // [NG][32 units][64 chunks] cell state
     // input-projection tile of the step: [NG][64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
     unsigned char *sG0 = reinterpret_cast<unsigned char *>(sC0 + NG * LG_UNITS * LG_BN);
@@ -1483,13 +1494,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 //   swap(v[0], v[2]) -> {r[0], r[1]} = low lanes {unit 0, unit 1}, high lanes {unit 4, unit 5}
                 //   swap(v[1], v[3]) -> low lanes {unit 2, unit 3}, high lanes {unit 6, unit 7}
 #pragma unroll
-                for (int part = 0; part < (NSPLIT == 3 ? 2 : 1); ++part) {
+                for (int part = 0; part < ((NSPLIT == 3 || (YALT && NSPLIT == 2)) ? 2 : 1); ++part) {
                     unsigned *v = part == 0 ? phi : plo;
                     auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
                     const unsigned e0 = r0[0], o0 = r0[1], e1 = r1[0], o1 = r1[1];
                     const int pr = wid * 4 + hsel * 2;                  // first unit pair of this lane
-                    unsigned *dst = sT + part * 16 * ST_LD + nt * 32 + (lane & 31);
+                    // (YALT, NSPLIT 2: the residual pairs are not part of the exchange image: they go to the y staging)
+                    unsigned *dst = ((YALT && NSPLIT == 2 && part == 1) ? sTy : sT + part * 16 * ST_LD) + nt * 32 + (lane & 31);
                     dst[(pr + 0) * ST_LD] = e0 | (o0 << 16);
                     dst[(pr + 1) * ST_LD] = e1 | (o1 << 16);
                 }
@@ -1504,7 +1516,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
                     dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
                 }
-                if (NSPLIT == 2 || I8) {
+                if (NSPLIT == 2 || I8 || (YALT && NSPLIT == 3)) {
                     // q8 image of the 32 units: 16 dword rows in the place of the lo staging -- rows 0..7 the h8 bytes of unit
                     // quads 0..7, rows 8..15 their l8 bytes, so the 16-byte cell reads below need no change.
                     // X = {h8(u_a), h8(u_b), l8(u_a), l8(u_b)} of this lane's units (rg 0, 1), Y of (rg 2, 3); after the swap
@@ -1514,7 +1526,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     Y = fp8_pair<true>(lq[2], lq[3], Y);
                     auto r = __builtin_amdgcn_permlane32_swap(X, Y, false, false);
                     const unsigned r0 = r[0], r1 = r[1];
-                    unsigned *dst = sT + 16 * ST_LD + nt * 32 + (lane & 31);
+                    unsigned *dst = ((YALT && NSPLIT == 3) ? sTy : sT + 16 * ST_LD) + nt * 32 + (lane & 31);
                     dst[(wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
                     dst[(8 + wid * 2 + hsel) * ST_LD] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
                 }
@@ -1536,6 +1548,11 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const unsigned *sl = src + 16 * ST_LD;
                     vlo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
                 }
+            }
+            uint4 vylo = vlo;            // second part of the layer output: the exchange image's, or (YALT) the other form
+            if (YALT) {
+                const unsigned *sl = sTy + (occ * 4) * ST_LD + orow;
+                vylo = make_uint4(sl[0], sl[ST_LD], sl[2 * ST_LD], sl[3 * ST_LD]);
             }
             if (s + 1 < T) {
                 // publish h_t for the group -- also on the last step of a launch: the next launch (next step, or next time
@@ -1585,10 +1602,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
                     if (XB_SIG(p.sig_flag)) {           // read by another stream's kernel while this launch is still running: write-through
                         store16_sc1(p.y_hi + o, vhi);
-                        store16_sc1(p.y_lo + o, vlo);
+                        store16_sc1(p.y_lo + o, vylo);
                     } else {
                         *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
-                        *reinterpret_cast<uint4 *>(p.y_lo + o) = vlo;
+                        *reinterpret_cast<uint4 *>(p.y_lo + o) = vylo;
                     }
                 }
             }
@@ -1640,12 +1657,12 @@ static size_t lstm_lds_bytes(int nsplit, bool dual)
            (size_t)ng * (sizeof(float) * LG_UNITS * LG_BN + (size_t)LG_BN * LG_UNITS * 16) + 16 + 80 + 256 * 16 + 128 * 4;
 }
 
-template <int KS, int NSPLIT, bool DUAL>
+template <int KS, int NSPLIT, bool DUAL, bool YALT = false>
 hipError_t launch_lstm_v(const xb::LstmParams &p, dim3 grid, size_t lds, hipStream_t stream)
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, NSPLIT, DUAL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_kernel<KS, NSPLIT, DUAL, YALT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((lstm_kernel<KS, NSPLIT, DUAL>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((lstm_kernel<KS, NSPLIT, DUAL, YALT>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -1664,6 +1681,12 @@ hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
         if (p.nsplit == 4) return dual ? launch_lstm_v<KS, 4, true>(p, grid, lds, stream) : launch_lstm_v<KS, 4, false>(p, grid, lds, stream);
         if (p.nsplit == 5) return dual ? launch_lstm_v<KS, 5, true>(p, grid, lds, stream) : launch_lstm_v<KS, 5, false>(p, grid, lds, stream);
     } else if (p.nsplit >= 4) {
+        return hipErrorInvalidValue;
+    }
+    // y_alt: the layer output carries the other second part than the exchange image (lstm_kernel YALT)
+    if (p.y_alt) {
+        if (p.nsplit == 3) return dual ? launch_lstm_v<KS, 3, true, true>(p, grid, lds, stream) : launch_lstm_v<KS, 3, false, true>(p, grid, lds, stream);
+        if (p.nsplit == 2) return dual ? launch_lstm_v<KS, 2, true, true>(p, grid, lds, stream) : launch_lstm_v<KS, 2, false, true>(p, grid, lds, stream);
         return hipErrorInvalidValue;
     }
     if (dual) {

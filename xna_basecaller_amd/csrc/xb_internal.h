@@ -116,7 +116,9 @@ struct GemmParams {
     float blank;
     int nsplit;                  // 3 = hi*hi + hi*lo + lo*hi ; 1 = hi*hi only ; 2 = hi*hi + fp8 corrections (q8 images)
     int a_exp, b_exp;            // nsplit == 2: exponents of the A and B q8 images
-    int out_exp;                 // nsplit == 2, EPI_SILU_SPLIT: exponent of the q8 image written to out_lo
+    int out_exp;                 // EPI_SILU_SPLIT, q8 output: exponent of the q8 image written to out_lo
+    int out_fmt;                 // EPI_SILU_SPLIT: second part of the output -- 0: this GEMM's own form (q8 image when nsplit == 2,
+                                 // else the fp16 residual), 1: fp16 residual, 2: q8 image (what the CONSUMING GEMM's arithmetic reads)
     int gin_n;                   // EPI_BIAS_F32: > 0 selects the member-major gin layout (below) with gin_n chunks per time step
     // gemm4p_kernel (two workgroups per CU, B straight from a fragment-major weight image, see xb_encoder.hip): used when b4
     // is set; otherwise gemm8r_kernel (one 256 x 256 workgroup per CU, both operands through LDS; kept as the A/B reference)
@@ -166,6 +168,9 @@ struct LstmParams {
     const int8_t *wq1, *wq0;     // nsplit == 4: (4F, F) balanced signed digits of round(W_hh / row scale * 32512), gate-interleaved rows
     const float *wscale;         // nsplit == 4: (4F) row scale / 32512^2: the factor that turns the integer digit sums into W_hh h
     int w_exp;                   // nsplit == 2: exponent of the W_hh q8 image
+    int y_alt;                   // 1 (nsplit 2 or 3): y_lo receives the OTHER second part than the exchange image -- the fp16
+                                 // residual when nsplit == 2, the q8 image (exponent 8) when nsplit == 3 -- for a next GEMM that
+                                 // runs in the other arithmetic
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
     int dual;                    // 1: a workgroup serves two groups alternately (a launch then holds twice the groups)
     int slab;                    // index of this launch among the layer's time slabs (selects the byte of the XCD mask below)

@@ -4,8 +4,14 @@ Output side of the basecaller: FASTQ records on stdout and one summary row per r
 Written from the OUTPUT FORMAT the reference produces (ub-bonito/bonito/io.py), not from its code:
 
   * stdout format is chosen from the name stdout is redirected to (io.py:30-49): `*.fq` / `*.fastq` / a tty / a pipe
-    mean FASTQ; `.sam` / `.bam` / `.cram` would mean alignment output, which needs pysam/mappy and is outside the
-    north-star path (SURVEY.md section 2 row 7) -- the CLI refuses those;
+    mean FASTQ; `.sam` means SAM text: the header (io.py:87-112: @HD VN:1.5 SO:unknown ob:0.0.1, @PG basecaller with version
+    and command line, the reads' @RG lines) and one UNALIGNED record per read (io.py:115-145 with mapping = False: flag 4,
+    `*` reference / CIGAR, NM:i:0, then the same tags as the FASTQ header) -- the reference hands both to pysam
+    (`AlignmentFile(fd, 'w', text=header)` / `AlignedSegment.fromstring`, io.py:391-401,432-437), whose SAM text mode prints the
+    header text as it is and each record as its own line; pysam is in no image, so the text is written directly.  The
+    reference's header also carries `@PG ID:aligner PN:minimap2 VN:<mappy version>` whether or not anything is aligned; here
+    that line is written only when an aligner version is given (none exists: mappy is in no image), so an unaligned file does
+    not claim an aligner.  `.bam` / `.cram` need htslib and aligned records need mappy: refused;
   * a FASTQ record is  "@<read_id> <tag>\\t<tag>...\\n<sequence>\\n+\\n<qstring>\\n"  (io.py:76-84) with the tags
     RG:Z:<run_id>_<model>  qs:i:<rounded mean q>  mx:i  ch:i  st:Z  rn:i  f5:Z  (io.py:412-419, fast5.py:118-128);
   * the summary is `<stdout stem>_summary.tsv` (`summary.tsv` on a tty or a pipe; io.py:148-155), tab separated with the
@@ -64,6 +70,32 @@ def write_fasta(header, sequence, fd=sys.stdout):
     fd.write(">%s\n%s\n" % (header, sequence))
 
 
+SAM_SPEC = "0.0.1"          # the reference's __ont_bam_spec__ (io.py:27)
+
+
+def sam_header(groups, sep="\t", version=None, argv=None, aligner_version=None):
+    """The SAM header text (io.py:87-112): @HD, @PG of the basecaller (PN:bonito -- the drop-in's program name -- with `version`
+    and the command line `argv`), optionally the aligner's @PG, then the read-group lines; lines joined by os.linesep, one
+    trailing newline."""
+    from . import __version__
+    lines = [sep.join(["@HD", "VN:1.5", "SO:unknown", "ob:%s" % SAM_SPEC]),
+             sep.join(["@PG", "ID:basecaller", "PN:bonito", "VN:%s" % (__version__ if version is None else version),
+                       "CL:bonito %s" % " ".join(sys.argv[1:] if argv is None else argv)])]
+    if aligner_version is not None:
+        lines.append(sep.join(["@PG", "ID:aligner", "PN:minimap2", "VN:%s" % aligner_version, "DS:mappy"]))
+    return "%s\n" % os.linesep.join(lines + list(groups))
+
+
+def sam_record(read_id, sequence, qstring, mapping=None, tags=None, sep="\t"):
+    """One SAM record as text (io.py:115-145).  Only the unaligned form exists here: flag 4, no reference, NM:i:0."""
+    if mapping:
+        raise NotImplementedError("aligned SAM records need a mappy alignment (minimap2 is in no image)")
+    record = [read_id, 4, "*", 0, 0, "*", "*", 0, 0, sequence, qstring, "NM:i:0"]
+    if tags is not None:
+        record.extend(tags)
+    return sep.join(map(str, record))
+
+
 def _tsv_field(value):
     """One field in csv.writer's default dialect with a tab delimiter (quote only when needed, double the quotes)."""
     text = "" if value is None else str(value)
@@ -116,15 +148,18 @@ def summary_row(read, seqlen, qscore):
 
 
 class Writer(Thread):
-    """Drains the (read, result) iterator on its own thread: FASTQ to `fd`, a summary row and a log entry per read."""
+    """Drains the (read, result) iterator on its own thread: FASTQ (mode 'wfq') or unaligned SAM text (mode 'w', header first)
+    to `fd`, a summary row and a log entry per read."""
 
     def __init__(self, mode, iterator, aligner=None, fd=sys.stdout, duplex=False, ref_fn=None, groups=None,
                  group_key=None, summary=None):
         super().__init__()
-        if mode != "wfq" or aligner is not None:
-            raise NotImplementedError("only unaligned FASTQ output is on the MI355X path (mode 'wfq')")
+        if mode not in ("wfq", "w") or aligner is not None or duplex:
+            raise NotImplementedError("unaligned FASTQ (mode 'wfq') and unaligned SAM text (mode 'w') are on the MI355X path; "
+                                      "BAM / CRAM need htslib, aligned records need mappy")
         self.mode, self.fd, self.iterator = mode, fd, iterator
         self.group_key = group_key
+        self.groups = sorted(groups) if groups else []
         self.summary = summary
         self.log = []
         self.error = None
@@ -140,13 +175,18 @@ class Writer(Thread):
             mean_q = mean_qscore_from_qstring(qstring)
         tags = ["RG:Z:%s_%s" % (read.run_id, self.group_key), "qs:i:%d" % round(mean_q)]
         tags += list(read.tagdata()) + list(res.get("mods", []))
-        write_fastq(read.read_id, seq, qstring, fd=self.fd, tags=tags)
+        if self.mode == "wfq":
+            write_fastq(read.read_id, seq, qstring, fd=self.fd, tags=tags)
+        else:
+            self.fd.write(sam_record(read.read_id, seq, qstring, res.get("mapping", False), tags=tags) + "\n")
         table.append(summary_row(read, len(seq), mean_q))
         self.log.append((read.read_id, len(read.signal)))
 
     def run(self):
         try:
             with SummaryTable(self.summary or summary_file()) as table:
+                if self.mode == "w":
+                    self.fd.write(sam_header(self.groups))
                 for read, res in self.iterator:
                     self._emit(table, read, res)
         except BaseException as e:  # surfaced by the CLI after join()

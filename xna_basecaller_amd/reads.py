@@ -100,6 +100,16 @@ def _read_tags(read):
             "rn:i:%s" % read.read_number, "f5:Z:%s" % read.filename]
 
 
+def _read_group(read, model):
+    """The read's @RG header line for SAM output (fast5.py:106-120): ID <run_id>_<model>, platform ONT, run start, flow cell,
+    device, sample (as library and as sample), and a description naming run and basecall model."""
+    fields = (("ID", "%s_%s" % (read.run_id, model)), ("PL", "ONT"), ("DT", getattr(read, "exp_start_time", "")),
+              ("PU", getattr(read, "flow_cell_id", "")), ("PM", getattr(read, "device_id", "None")),
+              ("LB", getattr(read, "sample_id", "None")), ("SM", getattr(read, "sample_id", "None")),
+              ("DS", "run_id=%s basecall_model=%s" % (read.run_id, model)))
+    return "\t".join(["@RG"] + ["%s:%s" % kv for kv in fields])
+
+
 class Read:
     """
     One nanopore read.  `raw` int16 DACs + attributes -> scaled pA -> trimmed -> normalised
@@ -147,6 +157,9 @@ class Read:
     def __repr__(self):
         return "Read('%s')" % self.read_id
 
+    def readgroup(self, model):
+        return _read_group(self, model)
+
     def tagdata(self):
         """FASTQ header tags of the read (fast5.py:118-128): mux, channel, start time, read number, source file."""
         return _read_tags(self)
@@ -172,6 +185,9 @@ class SyntheticRead:
 
     def __repr__(self):
         return "SyntheticRead('%s')" % self.read_id
+
+    def readgroup(self, model):
+        return _read_group(self, model)
 
     def tagdata(self):
         return _read_tags(self)
@@ -223,8 +239,9 @@ def _text(v, default=""):
     return str(v)
 
 
-def _fast5_read(filename, group):
-    """One read of a fast5 file -> Read.  The attribute set is the one fast5.py:24-76 consumes."""
+def _fast5_read(filename, group, meta=False):
+    """One read of a fast5 file -> Read (meta: attributes only, the signal is not touched -- fast5.py:222-233).  The attribute
+    set is the one fast5.py:24-76 consumes."""
     from . import hdf5_lite
     with hdf5_lite.File(filename) as f:
         if group.startswith("Raw/Reads/"):                   # single-read layout
@@ -247,19 +264,29 @@ def _fast5_read(filename, group):
             "start_mux": int(ra.get("start_mux", 0)), "read_number": int(ra.get("read_number", 0)),
             "start_time": int(ra.get("start_time", 0)),
         }
-        raw = raw_grp["Signal"][:]
-        attrs["duration"] = int(ra.get("duration", len(raw)))
-        return Read(raw, attrs, filename)
+        raw = None if meta else raw_grp["Signal"][:]
+        attrs["duration"] = int(ra.get("duration", 0 if raw is None else len(raw)))
+        return Read(raw, attrs, filename, meta=meta)
 
 
-def _load_read(job):
+def _load_read(job, meta=False):
     """(filename, key) -> Read; runs in a pool worker (fast5.py:263-270 get_raw_data_for_read)."""
     filename, key = job
     if str(filename).endswith(".fast5"):
-        return _fast5_read(filename, key)
+        return _fast5_read(filename, key, meta=meta)
     with np.load(filename) as z:
         attrs = json.loads(bytes(z["meta"]).decode())[key]
-        return Read(z["raw_%d" % key], attrs, filename)
+        return Read(None if meta else z["raw_%d" % key], attrs, filename, meta=meta)
+
+
+def get_read_groups(directory, model, read_ids=None, skip=False, n_proc=1, recursive=False, cancel=None):
+    """The set of @RG header lines of the selected reads (fast5.py:236-251): metadata only, no signal is read."""
+    groups = set()
+    for job in read_jobs(directory, read_ids=read_ids, skip=skip, recursive=recursive):
+        groups.add(_load_read(job, meta=True).readgroup(model))
+        if cancel is not None and cancel.is_set():
+            break
+    return groups
 
 
 def read_jobs(directory, read_ids=None, skip=False, recursive=False):
