@@ -56,12 +56,17 @@ def cpu_baseline(sd, features, n_base, L, chunks, alphabet, repeats=3):
                       % (chunks, L, n_base, repeats, "/".join("%.1f" % t for t in times))}
 
 
-def measured_traffic(kernel_prefix, nb, batch, chunksize, precision, launches_per_step):
-    """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE
-    collected in separate rocprofv3 runs, gfx950 correction applied) -- only when they were taken on this configuration.
-    The passes count bytes per bench step; they are divided by THIS run's launches per step (counter collection runs the
-    recurrence as slab launches, the timed run as one launch per layer: the bytes are the same, the launch count is not)."""
+def measured_traffic(kernel_prefix, nb, batch, chunksize, precision, launches_per_step, fused):
+    """(HBM bytes per launch, provenance) from the committed PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 runs, gfx950 correction applied).  The number is a REPLAY of a profile, not a count taken in
+    this run (counters cannot be collected inside the timed region), so it is only quoted when that profile was collected on
+    THIS code (the library's source digest, _lib.source_digest) and on this configuration and call pairing; otherwise null,
+    with the reason.  The passes count bytes per bench step; they are divided by THIS run's launches per step (counter collection
+    runs the recurrence as slab launches, the timed run as one launch per layer: the bytes are the same, the launch count not)."""
     import glob
+    from xna_basecaller_amd import _lib
+    digest = _lib.source_digest()
+    why = "no profile for this configuration under profiles/"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -70,12 +75,18 @@ def measured_traffic(kernel_prefix, nb, batch, chunksize, precision, launches_pe
         c = d.get("config", {})
         if (c.get("n_base"), c.get("batch_per_gpu"), c.get("chunksize"), c.get("precision")) != (nb, batch, chunksize, precision):
             continue
+        src = {"file": os.path.relpath(path, ROOT), "profile_source_digest": d.get("source_digest"), "running_source_digest": digest}
+        if d.get("source_digest") != digest:
+            why = "%s was collected on other code (source digest %s, running %s)" % (src["file"], d.get("source_digest"), digest)
+            continue
+        if bool(c.get("fuse", 1)) != bool(fused):
+            why = "%s was collected with%s call pairing" % (src["file"], "" if c.get("fuse", 1) else "out")
+            continue
         for name, k in d.get("kernels", {}).items():
-            if name.startswith(kernel_prefix):
-                if "steps" in d and launches_per_step > 0:
-                    return k.get("hbm_bytes_all_launches") / d["steps"] / launches_per_step
-                return k.get("hbm_bytes_per_launch")
-    return None
+            if name.startswith(kernel_prefix) and launches_per_step > 0 and "steps" in d:
+                src["kernel"] = name
+                return k.get("hbm_bytes_all_launches") / d["steps"] / launches_per_step, src
+    return None, {"reason": why, "running_source_digest": digest}
 
 
 def main():
@@ -224,11 +235,12 @@ def main():
     chunks_per_launch_factor = 5.0 * K / max(rec_launches, 1)       # calls served per recurrence launch of a layer (time slabs: < 1)
     fused = chunks_per_launch_factor > 1.5
     dual = (N > 512 or fused) and os.environ.get("XB_LSTM_DUAL", "1") != "0"
+    rec_traffic, rec_traffic_src = measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K), fused)
     roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false"),
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,
-                "traffic": measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K)),
+                "traffic": rec_traffic, "traffic_source": rec_traffic_src,
                 # what a launch has to move: its gin tiles in (fp32, 4F per chunk and step), the layer output out (hi + second part)
                 "algorithmic_bytes": 5.0 * K / max(rec_launches, 1) * float(T) * N * (4 * F * 4 + F * 4),
                 "avg_launch_ms": 1e3 * rec_avg_s, "launches": rec_launches, "launches_per_step": rec_launches / K,
@@ -240,9 +252,10 @@ def main():
     a_dec = float(T) * N * (3 * S * E * 4 + 7 * S * 4 + 1) * (K / max(dec_launches, 1))
     dec_avg_s = 1e-3 * dec_ms / max(dec_launches, 1)
     dec_gbs = a_dec / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
+    dec_traffic, dec_traffic_src = measured_traffic("crf_decode_kernel", nb, N, L, args.precision, dec_launches / float(K), fused)
     roofline_decode = {"kernel": "crf_decode_kernel", "bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": dec_gbs / HBM_PEAK_GBS,
-                       "traffic": measured_traffic("crf_decode_kernel", nb, N, L, args.precision, dec_launches / float(K)), "algorithmic_bytes": a_dec,
+                       "traffic": dec_traffic, "traffic_source": dec_traffic_src, "algorithmic_bytes": a_dec,
                        "avg_launch_ms": 1e3 * dec_avg_s, "launches": dec_launches,
                        "decode_only_samples_per_s": N * L / dec_avg_s if dec_avg_s > 0 else 0.0}
 

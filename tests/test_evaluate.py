@@ -47,7 +47,9 @@ def _gotoh(ref, seq):
             c["I"] += 1
             st = 0 if F[i][j] == H[i - 1][j] - 8 else 2
             i -= 1
-    return c, (bj - j) / max(m, 1), best
+    # coverage as util.py:410 takes it: len(alignment.traceback.ref) / len(ref) -- the traceback string has one character per
+    # alignment COLUMN ('-' where the reference does not take part), so insertions count
+    return c, sum(c.values()) / max(m, 1), best
 
 
 def test_accuracy_against_independent_gotoh():
@@ -75,11 +77,18 @@ def test_accuracy_against_independent_gotoh():
         assert abs(acc - (100.0 * want["="] / den if den else 0.0)) < 1e-9
         # the trace is an alignment of that score: 5 '=' - 4 'X' - (8 per gap + 4 per further gap column)
         assert score >= 5 * want["="] - 4 * want["X"] - 8 * (want["I"] + want["D"])
-        assert util.accuracy(ref, seq, min_coverage=cov + 1e-9) == 0.0 or cov >= 1.0
+        assert util.accuracy(ref, seq, min_coverage=cov + 1e-9) == 0.0
+        if den:
+            assert util.accuracy(ref, seq, min_coverage=cov - 1e-9) == acc
         bal = _lib.align_accuracy(ref, seq, balanced=True)
         d2 = want["="] + want["X"] + want["D"]
         assert abs(bal - (100.0 * (want["="] - want["I"]) / d2 if d2 else 0.0)) < 1e-9
     assert util.accuracy("ACGT" * 10, "ACGT" * 10) == 100.0 and util.accuracy("ACGT", "") == 0.0
+    # an insertion-rich call near the gate: 10 reference bases aligned over 12 columns -> coverage 1.2 of a 10-base reference
+    acc, c = _lib.align_accuracy("ACGTACGTAC", "ACGTATTCGTAC", want_counts=True)
+    assert c == {"=": 10, "X": 0, "I": 2, "D": 0} and util.accuracy("ACGTACGTAC", "ACGTATTCGTAC", min_coverage=1.1) == acc > 0
+    with pytest.raises(_lib.XbError):
+        _lib.align_accuracy("A" * 9000, "C" * 9000)                 # beyond the bounded DP: refused, not attempted
     assert util.decode_ref(np.array([1, 2, 0, 5, 6, 0]), list("NACGTXY")) == "ACXY"
 
 

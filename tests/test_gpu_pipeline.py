@@ -76,10 +76,13 @@ def test_basecall_reads_end_to_end():
     assert mism <= total // 500, (mism, total)
 
 
-def test_pipelined_device_calls_match_blocking_calls():
-    """Several xb_basecall_chunks_dev calls in flight (decode of batch k beside the encoder of batch k+1, time-slab
-    recurrence with the next layer's GEMM on the second stream), ONE synchronize at the end: every batch must equal
-    what the blocking host entry point returns for it.  T = 400 makes the recurrence run as 3 time slabs."""
+@pytest.mark.parametrize("decode_async", ["0", "1"])
+def test_pipelined_device_calls_match_blocking_calls(decode_async, monkeypatch):
+    """Several xb_basecall_chunks_dev calls in flight (time-slab recurrence with the next layer's GEMM on the second stream; the
+    decode of batch k on the main stream -- the default -- or, XB_DECODE_ASYNC=1, on a third stream beside the encoder of
+    batch k+1 with ping-pong score buffers), ONE synchronize at the end: every batch must equal what the blocking host entry
+    point returns for it.  T = 400 makes the recurrence run as 3 time slabs."""
+    monkeypatch.setenv("XB_DECODE_ASYNC", decode_async)
     import torch
     from conftest import encoder_shapes, seeded_state_dict
     from xna_basecaller_amd import _lib

@@ -593,28 +593,36 @@ def test_eval_loop_handoff_fastq_to_paf_tooling():
         assert row[col["cs"]].startswith(":10*ag:") and row[col["strand"]] in "+-"
 
 
-def test_bench_traffic_is_the_committed_bytes_per_step_over_this_runs_launches():
-    """bench.py's roofline.traffic: the PMC passes (profiles/*_pmc_hbm_traffic.json) count bytes over `steps` bench steps with
-    whatever launch structure the profiled run had; the bench line divides the per-step bytes by ITS OWN launches per step, and
-    only for the configuration the passes were taken on."""
+def test_bench_traffic_is_the_committed_bytes_per_step_over_this_runs_launches(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic is a REPLAY of committed PMC passes (profiles/*_pmc_hbm_traffic.json), not a count taken in the
+    run: it is quoted only for the configuration, the call pairing AND the code the passes were collected on (the
+    library's source digest), with its provenance beside it; otherwise null with the reason.  When quoted: the passes' bytes
+    per bench step over THIS run's launches per step."""
     import importlib.util
     from conftest import ROOT
+    from xna_basecaller_amd import _lib
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    import glob
-    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True)[0]
-    d = json.load(open(path))
-    c = d["config"]
-    name = next(k for k in d["kernels"] if k.startswith("lstm_kernel"))
-    per_step = d["kernels"][name]["hbm_bytes_all_launches"] / d["steps"]
-    got = bench.measured_traffic("lstm_kernel", c["n_base"], c["batch_per_gpu"], c["chunksize"], c["precision"], 2.5)
-    assert got == pytest.approx(per_step / 2.5)
-    assert bench.measured_traffic("lstm_kernel", c["n_base"], c["batch_per_gpu"] + 1, c["chunksize"], c["precision"], 2.5) is None
-    # the recurrence's measured bytes stay close to what it has to move (gin in, layer output out)
-    T, N, F = c["chunksize"] // 5, c["batch_per_gpu"], 768
-    algorithmic_per_step = 5.0 * T * N * (4 * F * 4 + F * 4)
-    assert 1.0 <= per_step / algorithmic_per_step < 1.15
+    digest = _lib.source_digest()
+    assert len(digest) == 12 and digest == _lib.source_digest()
+    prof = {"steps": 2, "source_digest": digest, "config": {"n_base": 6, "batch_per_gpu": 512, "chunksize": 10000, "precision": "mixed", "fuse": 1},
+            "kernels": {"lstm_kernel<48, 2, true, true>": {"hbm_bytes_all_launches": 3.4e11}}}
+    os.makedirs(tmp_path / "profiles")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    path = tmp_path / "profiles" / "r99_pmc_hbm_traffic.json"
+    path.write_text(json.dumps(prof))
+    got, src = bench.measured_traffic("lstm_kernel", 6, 512, 10000, "mixed", 2.5, True)
+    assert got == pytest.approx(3.4e11 / 2 / 2.5)
+    assert src["file"] == os.path.join("profiles", "r99_pmc_hbm_traffic.json") and src["profile_source_digest"] == digest
+    # another batch size, another pairing, other code: null, and the reason says why
+    for args, word in (((6, 513, 10000, "mixed", 2.5, True), "no profile"), ((6, 512, 10000, "mixed", 5.0, False), "pairing")):
+        got, src = bench.measured_traffic("lstm_kernel", *args)
+        assert got is None and word in src["reason"]
+    prof["source_digest"] = "0" * 12
+    path.write_text(json.dumps(prof))
+    got, src = bench.measured_traffic("lstm_kernel", 6, 512, 10000, "mixed", 2.5, True)
+    assert got is None and "other code" in src["reason"] and src["running_source_digest"] == digest
 
 
 class _FakePipelineModel:

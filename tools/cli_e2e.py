@@ -75,12 +75,12 @@ def main():
             env["XB_FUSE"] = fuse
         t0 = time.time()
         with open(out, "w") as fh:
-            r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir], cwd=ROOT,
+            r = subprocess.run([sys.executable, "-m", "xna_basecaller_amd", "basecaller", model_dir, reads_dir, "-v"], cwd=ROOT,
                                stdout=fh, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t0
         err = r.stderr.decode()
         print("== XB_FUSE=%s (reads %d x ~%d samples, batch %d)" % (fuse, args.reads, args.samples, args.batch))
-        print("\n".join(l for l in err.splitlines() if l.startswith(">"))[-1200:])
+        print("\n".join(l for l in err.splitlines() if l.startswith(">") and "model basecaller params" not in l)[-1500:])
         import hashlib
         digests.append(hashlib.sha1(open(out, "rb").read()).hexdigest())
         print("cli wall (incl. start-up and model load): %.1f s, rc %d, fastq %d bytes, sha1 %s"

@@ -7,7 +7,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xna_basecaller_amd import _lib           # noqa: E402  (source_digest only: no GPU is touched)
 
 
 def main():
@@ -20,6 +25,7 @@ def main():
     ap.add_argument("--precision", default="f16f8")
     ap.add_argument("--note", default="")
     ap.add_argument("--steps", type=int, default=2, help="bench steps the PMC passes covered (tools/pmc_gemm.sh: 2)")
+    ap.add_argument("--fuse", type=int, default=1, help="the passes ran with two calls co-scheduled per device pass (bench.py default)")
     args = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(args.pmcdir + "/p*/**/*counter_collection.csv", recursive=True):
@@ -45,7 +51,12 @@ def main():
                          "Infinity-Cache hits are counted.",
            "steps": args.steps,
            "config": {"n_base": args.nbase, "batch_per_gpu": args.batch, "chunksize": args.chunksize,
-                      "precision": args.precision},
+                      "precision": args.precision, "fuse": args.fuse},
+           # the code the counters were collected on: bench.py quotes them only while the library's sources still hash to this
+           "source_digest": _lib.source_digest(),
+           "schedule_note": "counter collection serialises kernels and runs the recurrence as slab launches (XB_LSTM_SIGNAL off "
+                            "under ROCPROF_COUNTER_COLLECTION): the BYTES a step moves are those of the timed schedule, the launch "
+                            "count is not -- bench.py divides the bytes per step by its own launches per step",
            "kernels": kernels}
     json.dump(out, open(args.out, "w"), indent=1)
     for k, v in kernels.items():

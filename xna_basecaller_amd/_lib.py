@@ -127,6 +127,21 @@ def align_accuracy(ref, seq, balanced=False, min_coverage=0.0, want_counts=False
     return (acc.value, dict(zip("=XID", counts))) if want_counts else acc.value
 
 
+def source_digest():
+    """sha1 (12 hex digits) over the library's sources (csrc/*.hip, *.h, Makefile and the public header): what bench.py and
+    tools/hbm_traffic.py record so that a counter profile is only ever quoted for the code it was collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")])
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "xna_basecaller.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def device_count():
     return int(load().xb_device_count())
 

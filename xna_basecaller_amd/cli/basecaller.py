@@ -159,6 +159,13 @@ def main(args):
     sys.stderr.write(f"> completed reads: {len(writer.log):0,d}\n")
     sys.stderr.write("> duration: %s\n" % timedelta(seconds=np.round(duration)))
     sys.stderr.write("> samples per second %.1E\n" % (num_samples / duration))
+    if args.verbose:
+        # beyond the reference's lines: what the device stage did -- chunks of chunksize samples, overlaps and stub chunks included
+        # (the reference's metric above counts READ samples); tools/cli_e2e.py compares this rate with bench.py's
+        chunks = getattr(model, "chunks_submitted", 0)
+        sys.stderr.write("> duration (s): %.2f\n" % duration)
+        sys.stderr.write("> chunks basecalled: %d x %d samples = %.3E chunk samples per second\n"
+                         % (chunks, model.config["basecaller"]["chunksize"], chunks * model.config["basecaller"]["chunksize"] / duration))
     sys.stderr.write("> done\n")
 
 
@@ -184,7 +191,9 @@ def argparser():
     parser.set_defaults(quantize=None)
     parser.add_argument("--overlap", default=None, type=int)
     parser.add_argument("--chunksize", default=None, type=int)
-    parser.add_argument("--batchsize", default=None, type=int)
+    parser.add_argument("--batchsize", default=None, type=int,
+                        help="chunks per device call; multiples of 512 are the efficient sizes on MI355X (a recurrence launch "
+                             "serves 64-chunk groups, 8 or 16 at a time: 513 chunks cost 34 %% more per chunk than 512)")
     parser.add_argument("--max-reads", default=0, type=int)
     parser.add_argument("--min-accuracy", default=0.95, type=float)
     parser.add_argument("--min-coverage", default=0.90, type=float)

@@ -421,6 +421,7 @@ class Model(torch.nn.Module):
         for collect_chunks.  The caller keeps at most one handle per slot in flight."""
         sig = self._as_signal(batch)
         ctx = self.context(sig.shape[1], sig.shape[0])
+        self.chunks_submitted = getattr(self, "chunks_submitted", 0) + sig.shape[0]
         return ctx, slot, ctx.submit_chunks(slot, sig, self.alphabet)
 
     def pipeline_depth(self, chunk_len, n):

@@ -2,7 +2,7 @@
 //
 // `bonito evaluate` scores every call with util.accuracy (ub-bonito/bonito/util.py:402-424):
 //     parasail.sw_trace_striped_32(seq, ref, 8, 4, parasail.dnafull) -> CIGAR -> '=' / ('=' + 'I' + 'X' + 'D') * 100,
-//     0 when the aligned part of the reference covers less than min_coverage of it.
+//     0 when the alignment (its columns, insertions included: util.py:410) is shorter than min_coverage of the reference.
 // parasail is a third-party CPU library that no image here has; this is a restatement of what that call computes -- a
 // Smith-Waterman local alignment with affine gaps (a gap of length k costs 8 + 4 (k - 1)), match + 5 / mismatch - 4 (the
 // A, C, G, T block of NUC.4.4 = parasail.dnafull) -- with two stated choices where the restatement cannot be pinned:
@@ -30,6 +30,9 @@ extern "C" XB_API int xb_align_accuracy(const char *ref, int ref_len, const char
     const int OPEN = 8, EXT = 4, MATCH = 5, MIS = -4;
     const int n = seq_len, m = ref_len;                 // rows: query (seq), columns: reference
     const size_t W = (size_t)m + 1;
+    // three full (n + 1) x (m + 1) int32 matrices (the trace-back needs them): bounded -- `bonito evaluate` aligns chunk-level
+    // calls of a few thousand bases; 2^26 cells = 768 MiB is far beyond that and far below what would exhaust the host
+    if ((size_t)(n + 1) * W > ((size_t)1 << 26)) return XB_ERR_NOMEM;
     const int NEG = -(1 << 28);
     // H: best score ending at (i, j); E: ... with a gap in the query (deletion, consumes ref); F: ... gap in the ref (insertion)
     std::vector<int32_t> H((size_t)(n + 1) * W, 0), E((size_t)(n + 1) * W, NEG), F((size_t)(n + 1) * W, NEG);
@@ -67,9 +70,12 @@ extern "C" XB_API int xb_align_accuracy(const char *ref, int ref_len, const char
             --i;
         }
     }
-    const int ref_aligned = bj - j;
     if (counts) memcpy(counts, c4, sizeof c4);
-    if ((double)ref_aligned / (double)m < min_coverage) return XB_OK;
+    // util.py:410: r_coverage = len(alignment.traceback.ref) / len(ref) -- the traceback string carries a '-' for every column
+    // the reference does not take part in, so its length is the number of alignment COLUMNS ('=', X, D and I), not of
+    // reference bases
+    const int columns = c4[0] + c4[1] + c4[2] + c4[3];
+    if ((double)columns / (double)m < min_coverage) return XB_OK;
     const double den = balanced ? (double)(c4[0] + c4[1] + c4[3]) : (double)(c4[0] + c4[1] + c4[2] + c4[3]);
     const double num = balanced ? (double)(c4[0] - c4[2]) : (double)c4[0];
     *accuracy = den > 0 ? 100.0 * num / den : 0.0;

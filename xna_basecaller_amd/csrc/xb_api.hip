@@ -122,6 +122,10 @@ struct xb_ctx {
     // (q8 image or fp16 residual) follows the stage that CONSUMES it.
     int ns_conv = 3, ns_in[5] = {3, 3, 3, 3, 3}, ns_rec[5] = {3, 3, 3, 3, 3}, ns_lin = 3;
     int in1_layers = 31;         // XB_IN1_LAYERS (diagnostic): layers whose input projection XB_PREC_F16F8_IN1 reduces
+    int decode_async = 0;        // XB_DECODE_ASYNC=1: the decode of a batch runs on the third stream beside the next batch's conv + first
+                                 // GEMM (rounds 2-3) instead of on the main stream with the chip to itself (round 4 default: the same step
+                                 // time at every batch size -- the step is bound by the kernels' summed CU-time -- and the decode at 0.49-0.52
+                                 // of the HBM roofline instead of 0.35-0.42: profiles/r04_decode_placement.txt)
     int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
 
@@ -219,7 +223,7 @@ int alloc_workspaces(xb_ctx *ctx, int cap)
     if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->gin2, (T * N + 64) * 4 * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->c_state, N * F);
     rc = rc ? rc : dev_alloc(ctx, &ctx->scores, T * N * Cmax);
-    if (ctx->overlap) rc = rc ? rc : dev_alloc(ctx, &ctx->scores2, T * N * (size_t)ctx->ld_nb);
+    if (ctx->overlap && ctx->decode_async) rc = rc ? rc : dev_alloc(ctx, &ctx->scores2, T * N * (size_t)ctx->ld_nb);
     rc = rc ? rc : dev_alloc(ctx, &ctx->alpha, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->beta, (T + 1) * N * S);
     rc = rc ? rc : dev_alloc(ctx, &ctx->bmax, (T + 1) * N * S);
@@ -719,6 +723,7 @@ int run_decode(xb_ctx *ctx, const float *d_scores, int T, int n, int has_blank, 
     }
 #ifdef XB_LSTM_STAMPS
     if (const char *e = getenv("XB_DECODE_STOP")) p.debug_stop = atoi(e);
+    if (const char *e = getenv("XB_DECODE_LINEAR_LDS")) p.debug_lds = atoi(e);
 #endif
     StageScope sc(ctx, XB_STAGE_DECODE, 1, st);
     hipError_t e = xb::launch_crf_decode(p, st);
@@ -802,6 +807,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
     if (const char *e = getenv("XB_LSTM_LOCAL")) ctx->lstm_local = atoi(e) != 0;
+    if (const char *e = getenv("XB_DECODE_ASYNC")) ctx->decode_async = atoi(e) != 0;
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
     if (const char *e = getenv("XB_LSTM_I8")) ctx->lstm_i8 = atoi(e) == 2 ? 2 : (atoi(e) != 0);
     if (const char *e = getenv("XB_GEMM4")) ctx->gemm4 = atoi(e) != 0;
@@ -1459,7 +1465,7 @@ static int launch_calls(xb_ctx *ctx, const xb_ctx::Call &a, const xb_ctx::Call *
     const float *sig2 = b ? b->signal : nullptr;
     int rc;
     hipStream_t rs;
-    if (!ctx->overlap || !ctx->stream3 || !ctx->scores2) {
+    if (!ctx->overlap || !ctx->stream3 || !ctx->scores2 || !ctx->decode_async) {
         rs = ctx->result_stream = ctx->stream;
         rc = run_encoder(ctx, a.signal, n, 0, ctx->scores, ctx->ld_nb, sig2, a.n);
         if (rc) return rc;

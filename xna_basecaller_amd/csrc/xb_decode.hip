@@ -468,7 +468,8 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
         }
         // per-lane constants of local edge r: destination state and staged-row index of its score
         // (e = 0: stay, j = i, column 0; e >= 1: j = jb + e - 1, column kk)
-        int dstj[EPER], midx[EPER];
+        int dstj[EPER], midx[EPER], qidx[EPER];
+        const bool stay0 = LPS == 1 || ph == 0;                    // local edge 0 is the stay edge
 #pragma unroll
         for (int r = 0; r < EPER; ++r) {
             const int e = (LPS == 1 ? 0 : ph * H) + r;
@@ -476,8 +477,22 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
             const int j = e == 0 ? i : (val ? jb + e - 1 : jb);
             dstj[r] = j;
             midx[r] = HB ? j * E + (e == 0 ? 0 : kk) : (e == 0 ? 0 : j * NB + kk - 1);
+            qidx[r] = j * E + ((r == 0 && stay0) ? 0 : kk);       // slot of the edge's Q value in the row being assembled
         }
-        const bool stay0 = LPS == 1 || ph == 0;                    // local edge 0 is the stay edge
+        int wi = i;                                                // slot of this lane's state in the beta vectors
+#ifdef XB_LSTM_STAMPS
+        // diagnostic build only (XB_DECODE_LINEAR_LDS=1, results are WRONG): every per-edge LDS access of this sweep at a
+        // lane-linear address, i.e. free of bank conflicts -- what the conflicts cost at most (profiles/r04_decode_lds_conflicts.txt)
+        if (p.debug_lds) {
+#pragma unroll
+            for (int r = 0; r < EPER; ++r) {
+                dstj[r] = tid % S;
+                midx[r] = (tid + BS * r) % cpad;
+                qidx[r] = (tid + BS * r) % cpad;
+            }
+            wi = tid % S;
+        }
+#endif
         // the Q row of step t is complete once every thread has passed the barrier of step t-1:
         // it is stored (coalesced 16-byte groups) during iteration t-1
         auto store_qrow = [&](int t) {
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
                 if (post_mode) {                                 // uniform, xb_crf_scans: the row carries P itself (stored here,
 #pragma unroll                                                   // so that P is dead before the logs in the decode proper)
                     for (int r = 0; r < EPER; ++r)
-                        if (r < kcnt && act) qs[dstj[r] * E + ((r == 0 && stay0) ? 0 : kk)] = P[r];
+                        if (r < kcnt && act) qs[qidx[r]] = P[r];
                 }
                 // the EPER logs of Q = log(P + 1e-8) and the log of the logsumexp, two at a time
                 float la[EPER + 1], lo[EPER + 1];
@@ -557,15 +572,14 @@ __global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
 #pragma unroll
                 for (int r = 0; r < EPER; ++r) {
                     if (r < kcnt) {
-                        const int k = (r == 0 && stay0) ? 0 : kk;
-                        if (act && !post_mode) qs[dstj[r] * E + k] = lo[r];
+                        if (act && !post_mode) qs[qidx[r]] = lo[r];
                         mm = maxf(mm, lo[r] + mjv[r]);
                     }
                 }
                 if (LPS == 2) mm = pair_max(mm);
                 if (ph == 0 && act) {
-                    sA[(t & 1) * S + i] = bv;
-                    sX[(t & 1) * S + i] = mm;
+                    sA[(t & 1) * S + wi] = bv;
+                    sX[(t & 1) * S + wi] = mm;
                     bmax[(size_t)t * sstride + i] = mm;
                     if (beta_out) beta_out[(size_t)t * sstride + i] = bv;
                 }

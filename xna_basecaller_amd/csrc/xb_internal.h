@@ -26,6 +26,7 @@ struct DecodeParams {
     int32_t *seq_len;             // (N) or nullptr
     char alphabet[8];
     int debug_stop;               // diagnostic builds only (XB_LSTM_STAMPS): return after sweep 1 / 2
+    int debug_lds;                // diagnostic builds only: sweep 2 with lane-linear (conflict-free) LDS addresses, WRONG results
 };
 hipError_t launch_crf_decode(const DecodeParams &p, hipStream_t stream);
 int decode_lanes_per_state(int S, int N);   // 1, 2 or 4 lanes serve one CRF state (env XB_DECODE_LPS overrides for tests)
