@@ -236,7 +236,10 @@ def main():
     fused = chunks_per_launch_factor > 1.5
     dual = (N > 512 or fused) and os.environ.get("XB_LSTM_DUAL", "1") != "0"
     rec_traffic, rec_traffic_src = measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K), fused)
-    roofline = {"kernel": "lstm_kernel<%d, %d, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false"),
+    # template arguments as rocprofv3 prints them: KS, NSPLIT, DUAL, YALT (mixed: the q8 recurrence writes the fp16 residual the
+    # three-product GEMMs read, xb_encoder.hip lstm_kernel)
+    roofline = {"kernel": "lstm_kernel<%d, %d, %s, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false",
+                                                           "true" if prec == _lib.XB_PREC_MIXED else "false"),
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": rec_tflops / MFMA_F16_PEAK_TFLOPS,

@@ -809,3 +809,23 @@ def test_eval_loop_accuracy_table_from_this_packages_fastq(tmp_path):
     # the headline numbers (README.md:139-143 reports them per model): UB accuracy = 100 - mean error at the UB, DNA = elsewhere
     ub_acc = {k: 100 - np.mean(v["only_ub"]) for k, v in g["error_rate_cuts"].items()}
     assert abs(ub_acc["XNA01/+"] - 100 * 4 / 7) < 1e-9 and abs(ub_acc["XNA01/-"] - 75.0) < 1e-9
+
+
+def test_default_precision_is_mixed_and_the_opt_ins_are_named(monkeypatch):
+    """the default arithmetic of Model (hence of the CLI) is `mixed` -- feed-forward projections in three fp16
+    products, recurrences in f16f8 -- and the faster / more exact forms are opt-ins by config.toml [basecaller] precision or the
+    XNA_PRECISION environment variable."""
+    from conftest import make_config
+    from xna_basecaller_amd import _lib
+    from xna_basecaller_amd.crf import Model
+    monkeypatch.delenv("XNA_PRECISION", raising=False)
+    assert Model(make_config(32)).precision == _lib.XB_PREC_MIXED == 4
+    cfg = make_config(32)
+    cfg["basecaller"] = dict(cfg.get("basecaller", {}), precision="f16f8")
+    assert Model(cfg).precision == _lib.XB_PREC_F16F8
+    monkeypatch.setenv("XNA_PRECISION", "f16x3")
+    assert Model(cfg).precision == _lib.XB_PREC_F16X3
+    assert set(_lib.PRECISIONS) == {"mixed", "f16x3", "f16", "f16f8", "f16f8i"}
+    monkeypatch.setenv("XNA_PRECISION", "fp64")
+    with pytest.raises(KeyError):
+        Model(cfg)

@@ -239,8 +239,21 @@ __device__ __forceinline__ void load_seg(const float *p, float (&r)[CNT])
     (void)o;
 }
 
-constexpr int RDEPTH = 8;     // register-ring depth (time steps in flight), sweep 2 (a whole staged row per step)
-constexpr int RDEPTH13 = 16;  // sweeps 1 and 3: a lane's ring entry is only E (or E/2) floats
+// Ring depths and occupancy (round 4, tools/r04_decode_variants.sh, profiles/r04_decode_variants.txt): with rings of 4 / 8 steps
+// (rounds 2-3: 8 / 16) the nb = 6 kernel fits 168 registers, i.e. three workgroups per CU instead of two (LDS allows three);
+// the pass over a co-scheduled pair's 1024 chunks gets 1.9 % (nb 6) / 3.5 % (nb 5) faster, 512 chunks are unchanged, and the
+// 1024-thread variants spill less.  The hint is a MINIMUM of three waves per SIMD (a 1024-thread workgroup needs four).
+#ifndef XB_DEC_RDEPTH          // (tuning builds override these)
+#define XB_DEC_RDEPTH 4
+#endif
+#ifndef XB_DEC_RDEPTH13
+#define XB_DEC_RDEPTH13 8
+#endif
+#ifndef XB_DEC_WAVES_ATTR
+#define XB_DEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+constexpr int RDEPTH = XB_DEC_RDEPTH;       // register-ring depth (time steps in flight), sweep 2 (a whole staged row per step)
+constexpr int RDEPTH13 = XB_DEC_RDEPTH13;   // sweeps 1 and 3: a lane's ring entry is only E (or E/2) floats
 constexpr int LRING = 128;    // arg-max partial ring (steps); finalised 64 at a time
 
 // coalesced row staging for sweep 2: NR 16-byte groups per thread, loaded RDEPTH steps ahead, written to LDS per step
@@ -294,7 +307,7 @@ struct Edges {
 // SCAN = true: the xb_crf_scans variant (optional beta / posterior outputs, early return after sweep 1 or 2); the decode
 // proper is compiled without those paths (measured: 1-2 % of the decode time when they are run-time branches).
 template <int NB, int BS, bool HB, int LPS, int VW, bool SCAN>
-__global__ __launch_bounds__(BS) void crf_decode_kernel(xb::DecodeParams p)
+__global__ __launch_bounds__(BS) XB_DEC_WAVES_ATTR void crf_decode_kernel(xb::DecodeParams p)
 {
     constexpr int E = NB + 1;
     constexpr int H = Edges<E, LPS>::H;
