@@ -19,7 +19,7 @@ from xna_basecaller_amd.synthetic import seeded_weights               # noqa: E4
 def run(N, sd, d_signal, env, steps=3):
     import torch
     os.environ.update(env)
-    ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, 10000, N, precision=_lib.XB_PREC_F16F8)
+    ctx = _lib.Context(0, 6, 3, 768, 19, 5, 5.0, 2.0, 10000, N, precision=_lib.XB_PREC_MIXED)
     for k in env:
         os.environ.pop(k)
     ctx.load_state_dict(sd)

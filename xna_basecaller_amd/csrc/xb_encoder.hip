@@ -837,6 +837,25 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         { const int c_ = cur; cur = nxt1; nxt1 = nxt2; nxt2 = c_; }                             \
     } while (0)
 
+    // ---- a wave whose 64 columns lie wholly in the padding behind the matrix (the CRF linear layer: 1296 = 5 x 256 + 16 columns,
+    //      i.e. three of the last N tile's four waves) has no products to add and nothing to store: it only keeps up its share of
+    //      the A tile's LDS-DMAs and the tile barriers -- the MFMA pipe and the weight loads it would have taken go to the CU's
+    //      other workgroup (round 4).
+    if (__builtin_amdgcn_readfirstlane(n0 + wid * 64 >= p.Nn ? 1 : 0)) {
+        dma_a(0, 0);
+        dma_a(nk > 1 ? 1 : 0, 1);
+        int c0 = 0, c1 = 1, c2 = 2;
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");      // A(t) landed; A(t + 1) may be in flight
+            __builtin_amdgcn_s_barrier();
+            dma_a(t + 2 < nk ? t + 2 : nk - 1, c2);
+            const int c_ = c0; c0 = c1; c1 = c2; c2 = c_;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
     // ---- prologue: A(0) B(0) A(1) B(1) in the loop's issue order
     int cur = 0, nxt1 = 1, nxt2 = 2;
     {
