@@ -252,6 +252,11 @@ def test_fast5_reader_equals_bundle_path(tmp_path, vbz, vlen):
     ids = {recs[1][1]["read_id"], recs[5][1]["read_id"]}
     assert sorted(r.read_id for r in xreads.get_reads(str(d5), read_ids=ids, n_proc=2)) == sorted(ids)
     assert [r.index for r in xreads.get_reads(str(d5), shard=(1, 2))] == [1, 3, 5]
+    # SAM read groups (fast5.py:236-251): metadata only -- the same @RG lines from the fast5 files and from the bundle
+    g5, gn = xreads.get_read_groups(str(d5), "m@v1"), xreads.get_read_groups(str(dn), "m@v1")
+    assert g5 == gn == {r.readgroup("m@v1") for r in a} and all(g.startswith("@RG\tID:") for g in g5)
+    assert xreads._load_read(xreads.read_jobs(str(d5))[0], meta=True).meta and not hasattr(
+        xreads._load_read(xreads.read_jobs(str(d5))[0], meta=True), "signal")
 
 
 def _need_libhdf5():
