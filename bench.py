@@ -262,6 +262,19 @@ def main():
                        "avg_launch_ms": 1e3 * dec_avg_s, "launches": dec_launches,
                        "decode_only_samples_per_s": N * L / dec_avg_s if dec_avg_s > 0 else 0.0}
 
+    # ---- the LSTM-input GEMMs: the largest kernel by SUMMED device time (they run slab by slab beside the recurrence, so their
+    #      in-situ durations include what the two kernels cost each other; XB_OVERLAP=0 gives the stand-alone figure)
+    gin_ms, gin_launches = stages["lstm_in"]
+    gemm_flop_step = 5 * 2.0 * T * N * (4 * F) * F                      # 4 718 592 FLOP per raw sample
+    gemm_tflops = gemm_flop_step * K / (1e-3 * gin_ms) / 1e12 if gin_ms > 0 else 0.0
+    products = {0: 3, 1: 1, 2: 2, 3: 2, 4: 3}[prec]                     # MFMA-rate units per algorithmic FLOP pair (f16f8: fp16 + FP8 at 2x)
+    roofline_gemm = {"kernel": "gemm4p_kernel<0, %d>" % {0: 3, 1: 1, 2: 2, 3: 2, 4: 3}[prec], "bound": "mfma",
+                     "achieved": gemm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / MFMA_F16_PEAK_TFLOPS,
+                     "mfma_rate_frac": products * gemm_tflops / MFMA_F16_PEAK_TFLOPS,
+                     "stage_ms_per_step": gin_ms / K, "launches_per_step": gin_launches / K,
+                     "note": "algorithmic fp32-equivalent FLOPs of the five input projections over their summed HIP-event time; "
+                             "mfma_rate_frac counts the products the arithmetic issues per FLOP pair"}
+
     out = {
         "metric": "raw signal samples/sec basecalled, chunksize 10k", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -284,7 +297,7 @@ def main():
                                  "calls through one pass of the encoder and the decode (two chunk groups per recurrence workgroup), "
                                  "XB_FUSE=0 runs every call on its own" % N) if fused else
                                 "a step = one asynchronous xb_basecall_chunks_dev of %d chunks, each run on its own" % N},
-        "roofline": roofline, "roofline_decode": roofline_decode,
+        "roofline": roofline, "roofline_decode": roofline_decode, "roofline_gemm": roofline_gemm,
         "stage_ms_per_step": {k: v[0] / K for k, v in stages.items()},
         "stage_note": "HIP-event time per stage on its own stream; lstm_in / linear run slab by slab on a second stream "
                       "beside the previous layer's recurrence, so the stages overlap and do not add up to ms_per_step",
