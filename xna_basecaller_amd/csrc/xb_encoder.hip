@@ -630,6 +630,12 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 // 47.9 ms per five GEMMs) and the workgroup shape (one 256 x 256 workgroup per CU, gemm8r: 50 ms) move it by a few percent:
 // the bytes per element are the lever that is left.
 // ======================================================================================
+#ifndef XB_GEMM_LATE_A           // 1: (three- and one-product kernels) a k-tile's LDS-DMA requests behind its first MFMA group (A/B builds)
+#define XB_GEMM_LATE_A 1
+#endif
+#ifndef XB_GEMM_DMA_ASM          // 1: gemm4p_kernel's A-tile LDS-DMA requests as inline asm (see dma_a); 0: the builtin (A/B builds)
+#define XB_GEMM_DMA_ASM 1
+#endif
 constexpr int G4_BM = 128, G4_BN = 256, G4_THREADS = 256;
 
 __device__ __forceinline__ bool gemm4_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
@@ -676,16 +682,28 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     }
     const unsigned char *const tA_hi = reinterpret_cast<const unsigned char *>(p.a_hi + (size_t)m0 * p.lda);
     const unsigned char *const tA_lo = reinterpret_cast<const unsigned char *>(p.a_lo + (size_t)m0 * p.lda);
+    // (XB_GEMM_DMA_ASM: the requests as inline asm -- wave-uniform base in an SGPR pair, 32-bit lane offset -- so that hipcc does not
+    //  book them as LDS events: with the builtin every wait for an A fragment in the k loop is lgkmcnt(0), i.e. all eight fragment
+    //  reads of a k-step are waited for before its first MFMA; hidden from the compiler it counts, and the MFMAs on the first two
+    //  row tiles start while the other two tiles' fragments are still in flight)
     auto dma_a = [&](int t, int stage) {
         const size_t kb = (size_t)t * (GBK * 2);
         unsigned char *dst = smem_raw + stage * STB + wid * 1024;
 #pragma unroll
         for (int part = 0; part < NPA; ++part)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+#if XB_GEMM_DMA_ASM
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(dst + part * PARTB + h * 4096));
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             ::"v"(offs[h]), "s"((part ? tA_lo : tA_hi) + kb), "s"(m0v) : "memory", "m0");
+#else
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)((part ? tA_lo : tA_hi) + kb + offs[h]),
                     (__attribute__((address_space(3))) void *)(dst + part * PARTB + h * 4096), 16, 0, 0);
+#endif
+            }
     };
 
     // ---- B: this wave's two 32-row blocks; lane byte offsets for block 0 / 1 (the pieces are immediates)
@@ -725,6 +743,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
 #define G4P_SB() __builtin_amdgcn_sched_barrier(0)
+    constexpr bool G4P_LATE_A = XB_GEMM_LATE_A != 0 && NSPLIT != 2;
     // fragments of two 32-row tiles (ih = 0: rows 0..63, ih = 1: rows 64..127) of one part and k-step / of the q8 image
 #define G4P_RD_H(d, sa, part, ih, ks)                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
@@ -762,7 +781,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         G4P_SB();                                                                               \
         __builtin_amdgcn_s_barrier();                                                           \
         G4P_SB();                                                                               \
-        dma_a(t2_, nxt2);                                                                       \
+        if constexpr (!G4P_LATE_A) dma_a(t2_, nxt2);                                            \
         if constexpr (NSPLIT == 2) {                                                            \
             /* fragments of the NEXT group are requested ahead of the last four MFMAs of the current one: hipcc forgets its */ \
             /* lgkmcnt bookkeeping at every asm statement and waits lgkmcnt(0) behind it, which is free once they landed */ \
@@ -798,26 +817,40 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_MFMA_END();                                                                     \
             G4P_LDB_GROUP(bS, b2, 1);                                                           \
         } else {                                                                                \
-            /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi */ \
+            /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi.         */ \
+            /* The A fragments of the two row-tile pairs (ih = 0: rows 0..63, ih = 1: rows 64..127) are software-pipelined by  */ \
+            /* half k-steps (round 4): the reads for (ks + 1, ih) go out right behind the MFMAs of (ks, ih) and have the other  */ \
+            /* pair's twelve MFMAs to land; only the tile's first reads -- behind the barrier -- are waited for.  The order of */ \
+            /* the vector-memory instructions (hence every counted vmcnt) is unchanged.                                         */ \
+            half8 ah0[2], al0[2], ah1[2], al1[2];                                               \
+            G4P_RD_H(ah0, sa, 0, 0, 0);                                                         \
+            if (NSPLIT == 3) G4P_RD_H(al0, sa, 1, 0, 0);                                        \
+            G4P_RD_H(ah1, sa, 0, 1, 0);                                                         \
+            if (NSPLIT == 3) G4P_RD_H(al1, sa, 1, 1, 0);                                        \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                  \
-                half8 ah0[2], al0[2], ah1[2], al1[2];                                           \
-                G4P_RD_H(ah0, sa, 0, 0, ks);                                                    \
-                if (NSPLIT == 3) G4P_RD_H(al0, sa, 1, 0, ks);                                   \
+                /* (G4P_LATE_A: the tile's LDS-DMA requests go out behind its first twelve MFMAs instead of in front of them, */ \
+                /*  so the first wait has NA fewer younger operations)                                                        */ \
+                constexpr int LA_ = G4P_LATE_A ? NA : 0;                                        \
                 if (NSPLIT == 3) {                                                              \
-                    if (ks == 0) G4P_WAIT4(INFL - 4, bS[0][0], bS[1][0], bS[0][2], bS[1][2]);   \
+                    if (ks == 0) G4P_WAIT4(INFL - 4 - LA_, bS[0][0], bS[1][0], bS[0][2], bS[1][2]); \
                     else G4P_WAIT4(INFL - 4, bS[0][1], bS[1][1], bS[0][3], bS[1][3]);           \
                 } else {                                                                        \
-                    if (ks == 0) G4P_WAIT2(INFL - 2, bS[0][0], bS[1][0]);                       \
+                    if (ks == 0) G4P_WAIT2(INFL - 2 - LA_, bS[0][0], bS[1][0]);                 \
                     else G4P_WAIT2(INFL - 2, bS[0][1], bS[1][1]);                               \
                 }                                                                               \
-                G4P_RD_H(ah1, sa, 0, 1, ks);                                                    \
-                if (NSPLIT == 3) G4P_RD_H(al1, sa, 1, 1, ks);                                   \
                 G4P_MFMA_BEGIN();                                                               \
                 if (NSPLIT == 3) {                                                              \
                     G4P_F16(al0, 0, bS, ks);                                                    \
                     G4P_F16(ah0, 0, bS, 2 + ks);                                                \
                 }                                                                               \
                 G4P_F16(ah0, 0, bS, ks);                                                        \
+                G4P_MFMA_END();                                                                 \
+                if (ks == 0) {                                                                  \
+                    if constexpr (G4P_LATE_A) dma_a(t2_, nxt2);                                 \
+                    G4P_RD_H(ah0, sa, 0, 0, 1);                                                 \
+                    if (NSPLIT == 3) G4P_RD_H(al0, sa, 1, 0, 1);                                \
+                }                                                                               \
+                G4P_MFMA_BEGIN();                                                               \
                 if (NSPLIT == 3) {                                                              \
                     G4P_F16(al1, 1, bS, ks);                                                    \
                     G4P_F16(ah1, 1, bS, 2 + ks);                                                \
@@ -825,6 +858,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 G4P_F16(ah1, 1, bS, ks);                                                        \
                 G4P_MFMA_END();                                                                 \
                 if (ks == 0) {                                                                  \
+                    G4P_RD_H(ah1, sa, 0, 1, 1);                                                 \
+                    if (NSPLIT == 3) G4P_RD_H(al1, sa, 1, 1, 1);                                \
                     G4P_LDB_GROUP(bS, b2, 0);                                                   \
                     if (NSPLIT == 3) G4P_LDB_GROUP(bS, b2, 2);                                  \
                 } else {                                                                        \
@@ -930,16 +965,39 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 // (bounded spin), workgroup barrier, then EVERY load of the exchanged bytes is an sc1 load
 // (LDS-DMA with the sc1 bit), so no L1 line can be stale and no fence is needed.
 // ======================================================================================
+#ifndef XB_LSTM_DMA_ASM          // 1: the exchange pieces' LDS-DMA requests as inline asm (see dma16_sc1); 0: the builtin (A/B builds)
+#define XB_LSTM_DMA_ASM 1
+#endif
 constexpr int LG_BN = 64;        // chunks per group (2 MFMA column tiles)
 constexpr int LG_UNITS = 32;     // hidden units per member workgroup
 constexpr unsigned long long LG_SPIN_CYCLES = 4000000000ull;   // ~2 s at 2 GHz
 constexpr int CPOL_SC1 = 16;     // gfx940+ cache-policy immediate: sc0 = 1, nt = 2, sc1 = 16
 constexpr int ST_LD = 68;        // dword stride of one unit-pair row of the h staging (64 chunks + 4: 2-way reads)
 
+// (Inline asm, not __builtin_amdgcn_global_load_lds: hipcc books an LDS-DMA as an LDS event of the lgkm counter, and with two
+// kinds of events pending it can no longer count -- every wait for a B fragment in the MFMA loop became lgkmcnt(0), i.e. the
+// fragment reads issued one k-step AHEAD were waited for at once and their latency (~120 cycles per k-step pair, ~3 k cycles per
+// group-step) sat on the critical path.  Hidden from the compiler, the requests leave its bookkeeping alone and it emits the
+// counted waits the software pipeline needs; completion is the explicit s_waitcnt vmcnt(0) + barrier that closes every piece.)
 __device__ __forceinline__ void dma16_sc1(const void *g, void *lds_wave_base)
 {
+#if XB_LSTM_DMA_ASM
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(g), "s"(m0v) : "memory", "m0");
+#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, CPOL_SC1);
+#endif
+}
+// the same with a wave-uniform base (an SGPR pair) and a 32-bit per-lane byte offset: no 64-bit address arithmetic per request
+__device__ __forceinline__ void dma16_sc1_off(const void *ubase, int byte_off, void *lds_wave_base)
+{
+#if XB_LSTM_DMA_ASM
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"(byte_off), "s"(ubase), "s"(m0v) : "memory", "m0");
+#else
+    dma16_sc1(reinterpret_cast<const unsigned char *>(ubase) + byte_off, lds_wave_base);
+#endif
 }
 
 // 16-byte plain store: the line stays in the XCD's L2 (same asm form as the write-through one below)
@@ -975,6 +1033,10 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
 // hand-off (stores reaching L2, the other members' arrivals, the poll) then completes while the workgroup runs the other
 // group's step, the first h piece of the coming group-step is requested before the gate math of the current one, and
 // the gin tile is requested a whole group-step ahead: a launch holds twice the chunks at the same residency.
+#ifndef XB_LSTM_DMA_SPREAD       // 1: every LDS-DMA request of the MFMA loop directly behind one MFMA; 0 (default): in pairs behind the k-step's
+                                 // MFMAs -- measured on one box (profiles/r04_lstm_loop_ab.txt): no gain on top of XB_LSTM_DMA_ASM, a loss with one group per workgroup
+#define XB_LSTM_DMA_SPREAD 0
+#endif
 #ifdef XB_NO_SIGNAL
 #define XB_SIG(x) false
 #else
@@ -1202,10 +1264,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             // byte image: row stride F bytes inside a part region of XPART * 2 bytes; lane_off_step is in bytes here
             const unsigned char *base = reinterpret_cast<const unsigned char *>(xprev) + (size_t)part * (XPART * 2) +
                                         (size_t)(RPI * q) * F + pc * KP;                       // uniform
-            dma16_sc1(base + lane_off, dst);
+            dma16_sc1_off(base, lane_off, dst);
         } else if (POW2) {
             const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
-            dma16_sc1(base + lane_off, dst);
+            dma16_sc1_off(base, lane_off * 2, dst);
         } else {
             const int cell = 64 * q + lo;
             const int row = cell / CPR, pos = cell % CPR;
@@ -1406,6 +1468,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
                         if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
                         __builtin_amdgcn_sched_barrier(0);
+                        // The next piece's requests, two per k-step so that the last one is issued by mid-piece and has landed at
+                        // the barrier.  (XB_LSTM_DMA_SPREAD: every request directly behind ONE MFMA -- behind the FP8 ones, which
+                        // keep the pipe busy for 64 cycles, where the k-step has them -- instead of in pairs behind the k-step's
+                        // MFMAs: measured, not adopted.)
+                        auto dma_slot = [&](int j) {
+                            if (2 * ks + j >= NDMA) return;
+                            if (pc + 1 < NP) issue_dma(xprev, pc + 1, 2 * ks + j);
+                            else if (EIL && go) issue_dma(xnext, 0, 2 * ks + j);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        constexpr bool XB_DMA_SPREAD = XB_LSTM_DMA_SPREAD != 0;
+                        const bool q_step = NSPLIT == 2 && (ks & 1) == 1;
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
                             if (NSPLIT == 3) {
@@ -1413,21 +1487,21 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[kg], fl[ks & 1][nt], acc[nt], 0, 0, 0);
                             }
                             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kg == 0 ? w0 : wh[kg], fh[ks & 1][nt], acc[nt], 0, 0, 0);
+                            if (XB_DMA_SPREAD) __builtin_amdgcn_sched_barrier(0);      // (pins the MFMA order: hipcc otherwise pairs
+                            if (XB_DMA_SPREAD && !q_step) dma_slot(nt);                //  each column tile's dependent fp16 / FP8 MFMAs)
                         }
-                        if (NSPLIT == 2 && (ks & 1) == 1) {
+                        if (q_step) {
 #pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
+                            for (int nt = 0; nt < 2; ++nt) {
                                 acc[nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[kg >> 1], fq[nt], acc[nt], 0, 0, 0, sca, 0, scb);
+                                if (XB_DMA_SPREAD) __builtin_amdgcn_sched_barrier(0);
+                                if (XB_DMA_SPREAD) dma_slot(nt);
+                            }
                         }
-                        // two per k-step so that the last one is issued by mid-piece and has landed at the barrier
-                        if (pc + 1 < NP) {
-                            if (2 * ks < NDMA) issue_dma(xprev, pc + 1, 2 * ks);
-                            if (2 * ks + 1 < NDMA) issue_dma(xprev, pc + 1, 2 * ks + 1);
-                        } else if (EIL && go) {
-                            if (2 * ks < NDMA) issue_dma(xnext, 0, 2 * ks);
-                            if (2 * ks + 1 < NDMA) issue_dma(xnext, 0, 2 * ks + 1);
+                        if (!XB_DMA_SPREAD) {
+                            dma_slot(0);
+                            dma_slot(1);
                         }
-
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     }
