@@ -128,6 +128,10 @@ struct xb_ctx {
                                  // of the HBM roofline instead of 0.35-0.42: profiles/r04_decode_placement.txt)
     int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
+    int lstm_quad = 0;           // XB_LSTM_QUAD=1: the two-groups-per-workgroup launches run the software-pipelined kernel of xb_lstm_quad.h
+                                 // where it applies (F = 768, q8 exchange image).  Bit-identical and SLOWER (41.9 vs 31.0 ms per layer of
+                                 // 1024 chunks): an experiment kept for its measurements, never the default
+    int lstm_quad_res = -1;      // its occupancy (queried once)
 
     // Two asynchronous basecalls in flight are co-scheduled once the caller has opted in with xb_reserve_pairing (contexts of at
     // most 512 chunks; XB_FUSE=0 refuses): the first xb_basecall_chunks_dev of a pair is held back until the second arrives, then
@@ -506,6 +510,9 @@ int sync_all(xb_ctx *ctx);
 // Recurrence of one layer from `gin` into (xout_hi, xout_lo).  With `next` set, the GEMM that consumes this layer's output
 // is issued as well: either afterwards on the main stream, or -- overlapped mode -- slab by slab on the second stream while
 // the recurrence (192 of the 256 CUs, latency bound) is still running; the main stream then waits for the last slab.
+// group slots of the arrival counters: 64 groups of 64 chunks, or (lstm_quad_kernel) 128 groups of 32
+constexpr int SYNC_SLOTS = 128;
+
 int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout_hi, half_t *xout_lo, const NextGemm *next)
 {
     const int F = ctx->cfg.features, T = ctx->T;
@@ -538,6 +545,10 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
         p.nsplit = ctx->lstm_i8 == 2 ? 5 : 4; p.wq1 = ctx->whh_q1[layer]; p.wq0 = ctx->whh_q0[layer]; p.wscale = ctx->whh_sc[layer];
     }
     if (const char *e = getenv("XB_LSTM_SPREAD")) p.spread = atoi(e) != 0;
+    // the software-pipelined kernel serves the launches that put two groups of 64 on a workgroup (as four groups of 32)
+    bool quad_ok = ctx->lstm_quad && F == 768 && p.nsplit == 2 && !i8;
+    if (quad_ok && ctx->lstm_quad_res < 0) ctx->lstm_quad_res = xb::lstm_quad_resident_per_cu();
+    quad_ok = quad_ok && ctx->lstm_quad_res >= 1;
     bool overlapped = false;
     if (mode == 2) {
         // a workgroup can serve two groups alternately (lstm_kernel DUAL): a launch then holds 2 * gmax groups, and a
@@ -555,7 +566,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
         if (!overlapped) nts = 1;
         int launches = 0;
         for (int n0 = 0; n0 < n; n0 += slab) launches += nts;
-        if (global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
+        if (global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * SYNC_SLOTS * 32, ctx->stream));
         // One launch over all steps that reports its time slabs: the GEMM stream waits on the flag word instead of on an event
         // behind a slab launch, so the recurrence is not relaunched 16 times per layer (each relaunch costs ~30 us: its
         // workgroups find their CUs taken by GEMM workgroups that slipped in at the boundary).
@@ -575,6 +586,7 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                 StageScope sc(ctx, XB_STAGE_LSTM_REC, 1);
                 p.n0 = 0; p.nslab = n; p.s_begin = 0; p.s_end = T; p.persistent = 1;
                 p.dual = dual_batch && (ctx->lstm_dual == 2 ? n > bn : n > gslab * bn);
+                p.quad = p.dual && quad_ok;
                 p.grp0 = 0; p.slab = 0; p.xcd_local = ctx->lstm_local; p.sync_base = 0;
                 p.sig_flag = ctx->sig_flag; p.sig_done = ctx->sig_done; p.sig_base = ctx->sig_seq; p.sig_nts = nts;
                 XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
@@ -604,12 +616,13 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
                     p.s_begin = s0; p.s_end = s1; p.persistent = 1;
                     // a tail slab that fits the single-group launch gets one workgroup per group (twice the CUs at work)
                     p.dual = dual_batch && (ctx->lstm_dual == 2 ? p.nslab > bn : p.nslab > gslab * bn);
+                    p.quad = p.dual && quad_ok;
                     // counters are zeroed once per layer (above): consecutive launches follow each other without a memset in
                     // between, so the next launch's workgroups are dispatched the moment the previous one retires
                     p.grp0 = global_groups ? n0 / bn : 0;
                     p.slab = i; p.xcd_local = ctx->lstm_local && i < 16;   // 16 mask bytes per group slot
                     p.sync_base = global_groups ? arrivals : 0;
-                    if (!global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * 64 * 32, ctx->stream));
+                    if (!global_groups) XB_HIP(ctx, hipMemsetAsync(ctx->sync, 0, sizeof(unsigned) * SYNC_SLOTS * 32, ctx->stream));
                     XB_HIP(ctx, xb::launch_lstm(p, ctx->stream));
                 }
             }
@@ -806,6 +819,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     }
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
+    if (const char *e = getenv("XB_LSTM_QUAD")) ctx->lstm_quad = atoi(e) != 0;
     if (const char *e = getenv("XB_LSTM_LOCAL")) ctx->lstm_local = atoi(e) != 0;
     if (const char *e = getenv("XB_DECODE_ASYNC")) ctx->decode_async = atoi(e) != 0;
     if (const char *e = getenv("XB_IN1_LAYERS")) ctx->in1_layers = atoi(e) & 31;
@@ -859,15 +873,15 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     const size_t F = cfg->features;
     int rc = alloc_workspaces(ctx, cfg->max_batch);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);
-    rc = rc ? rc : dev_alloc(ctx, &ctx->sync, (size_t)64 * 32 + 32 + 64);      // group slots, error word, slab arrival counters
+    rc = rc ? rc : dev_alloc(ctx, &ctx->sync, (size_t)SYNC_SLOTS * 32 + 32 + 64);      // group slots, error word, slab arrival counters
     if (rc) {
         g_create_error = ctx->err;
         xb_ctx_destroy(ctx);
         return rc;
     }
-    ctx->error = ctx->sync + 64 * 32;
-    XB_CREATE_HIP(hipMemset(ctx->sync, 0, sizeof(unsigned) * (64 * 32 + 32 + 64)));
-    ctx->sig_done = ctx->sync + 64 * 32 + 32;
+    ctx->error = ctx->sync + SYNC_SLOTS * 32;
+    XB_CREATE_HIP(hipMemset(ctx->sync, 0, sizeof(unsigned) * (SYNC_SLOTS * 32 + 32 + 64)));
+    ctx->sig_done = ctx->sync + SYNC_SLOTS * 32 + 32;
     if (ctx->lstm_signal) {
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !can) {

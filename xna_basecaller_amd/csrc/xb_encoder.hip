@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "xb_internal.h"
 
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 #endif
 constexpr int LG_BN = 64;        // chunks per group (2 MFMA column tiles)
 constexpr int LG_UNITS = 32;     // hidden units per member workgroup
+constexpr int LG_SYNC = 64;      // words between the counter slots of consecutive 64-chunk groups (lstm_quad_kernel's 32-chunk groups: 32)
 constexpr unsigned long long LG_SPIN_CYCLES = 4000000000ull;   // ~2 s at 2 GHz
 constexpr int CPOL_SC1 = 16;     // gfx940+ cache-policy immediate: sc0 = 1, nt = 2, sc1 = 16
 constexpr int ST_LD = 68;        // dword stride of one unit-pair row of the h staging (64 chunks + 4: 2-way reads)
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     auto serve = [&](int gi) {
         const int g = grp + gi * gh;
         cbase = p.n0 + g * LG_BN;
-        cnt = p.sync + (size_t)(p.grp0 + g) * 32;
+        cnt = p.sync + (size_t)(p.grp0 + g) * LG_SYNC;
         xg = p.xh + (size_t)(p.grp0 + g) * (2 * 2 * LG_BN * F);
         sC = sC0 + gi * (LG_UNITS * LG_BN);
         sG = sG0 + gi * (LG_BN * LG_UNITS * 16);
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     if (p.persistent && p.xcd_local && tid == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;        // HW_REG_XCC_ID[3:0]
         for (int gi = 0; gi < (second ? 2 : 1); ++gi)
-            __hip_atomic_fetch_or(p.sync + (size_t)(p.grp0 + grp + gi * gh) * 32 + 1 + ((p.slab >> 2) & 3), 1u << (8 * (p.slab & 3) + xcc),
+            __hip_atomic_fetch_or(p.sync + (size_t)(p.grp0 + grp + gi * gh) * LG_SYNC + 1 + ((p.slab >> 2) & 3), 1u << (8 * (p.slab & 3) + xcc),
                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) { sFlag[2] = 0; sFlag[3] = 0; }
@@ -1298,7 +1300,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             const int ns = (DUAL && gi == 0 && second) ? s : s + 1;
             const bool nxt_h = DUAL && ns < p.s_end && ns > 0 && s > 0;
             const bool nxt_poll = p.persistent && ns > p.s_begin;
-            unsigned *ncnt = p.sync + (size_t)(p.grp0 + grp + ngi * gh) * 32;
+            unsigned *ncnt = p.sync + (size_t)(p.grp0 + grp + ngi * gh) * LG_SYNC;
             const unsigned ntarget = (unsigned)members * (p.sync_base + (unsigned)(ns - p.s_begin));
             unsigned seen = 0;
             const half_t *xnext = p.xh + (size_t)(p.grp0 + grp + ngi * gh) * (2 * 2 * LG_BN * F) + (size_t)((ns - 1) & 1) * XPAR;
@@ -1565,7 +1567,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const float gg = fast_tanh(acc[nt][4 * rg + 2]);
                     const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
                     float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
-                    const float cn = fg * *cp + ig * gg;
+                    const float cn = __builtin_fmaf(ig, gg, fg * *cp);     // spelled out: lstm_quad_kernel must round the same way
                     *cp = cn;
                     const float hv = og * fast_tanh(cn);
                     half_t hi, lo;
@@ -1737,6 +1739,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     }
 }
 
+#include "xb_lstm_quad.h"
+
 // dynamic LDS of lstm_kernel<KS, nsplit, dual>
 template <int KS>
 static size_t lstm_lds_bytes(int nsplit, bool dual)
@@ -1763,6 +1767,9 @@ template <int KS>
 hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 {
     constexpr int F = KS * 16;
+    if constexpr (KS == Q_KS) {
+        if (p.quad) return launch_lstm_quad(p, stream);
+    }
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const bool dual = p.dual != 0;
     const int gh = dual ? (ngroups + 1) / 2 : ngroups;      // workgroup slots (lstm_kernel)
@@ -1935,6 +1942,7 @@ int lstm_resident_per_cu(int F, int nsplit, int dual)
     }
 }
 
+int lstm_quad_resident_per_cu() { return lstm_quad_occupancy(); }
 int lstm_members(int F) { return F / LG_UNITS; }
 int lstm_group_chunks() { return LG_BN; }
 
@@ -1945,6 +1953,7 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
     if (p.nsplit < 1 || p.nsplit > 5) return hipErrorInvalidValue;
     if (p.nsplit >= 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
+    if (p.quad && (p.F != Q_F || p.nsplit != 2 || !p.persistent || !p.dual)) return hipErrorInvalidValue;
     if (p.sig_flag && (!p.persistent || p.s_begin != 0 || p.s_end != p.T || !p.sig_done || p.sig_nts < 1 || p.sig_nts > p.T))
         return hipErrorInvalidValue;
     switch (p.F / 16) {

@@ -160,7 +160,7 @@ struct LstmParams {
     int reverse;                 // time runs T-1..0
     int s_begin, s_end;          // recurrence steps [s_begin, s_end) of this launch (s = 0 is the first step)
     int persistent;              // 1: all steps in one launch with inter-workgroup sync
-    unsigned *sync;              // per-group monotonic arrival counters, stride 32 words (zeroed once per layer and chunk slab)
+    unsigned *sync;              // per-group monotonic arrival counters, 64 words per 64-chunk group slot (zeroed once per layer and chunk slab)
     unsigned sync_base;          // arrivals per member already counted by earlier launches of this layer (time slabs)
     unsigned *error;             // set non-zero when a sync wait timed out
     int nsplit;                  // as GemmParams::nsplit (2: w_lo, y_lo and the exchange "lo" part are q8 images, h exponent 8);
@@ -174,6 +174,9 @@ struct LstmParams {
                                  // runs in the other arithmetic
     int spread;                  // 1: spread each group's members over all XCDs (placement-independence test)
     int dual;                    // 1: a workgroup serves two groups alternately (a launch then holds twice the groups)
+    int quad;                    // 1 (with dual, F = 768, nsplit 2, persistent): the software-pipelined kernel of xb_lstm_quad.h -- four
+                                 // groups of 32 chunks per workgroup, the gate math of one group-step between the MFMAs of the next; the
+                                 // exchange buffer and the counters are then indexed in 32-chunk groups (slot 2 grp0 + g, 128 slots)
     int slab;                    // index of this launch among the layer's time slabs (selects the byte of the XCD mask below)
     int xcd_local;               // 1: members prove per launch that their group sits on one XCD (words 1..4 of the group's sync
                                  // slot, one byte per time slab, zeroed with the counters) and then exchange h with plain stores
@@ -190,6 +193,7 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream);
 // workgroups of the persistent kernel the occupancy calculator admits per CU for feature size F (0: the kernel cannot be
 // resident at all, e.g. LDS or registers taken by another tenant's limits); the persistent mode needs >= 1
 int lstm_resident_per_cu(int F, int nsplit, int dual);
+int lstm_quad_resident_per_cu();   // the same for the software-pipelined kernel (F = 768, nsplit 2)
 int lstm_members(int F);
 int lstm_group_chunks();
 bool lstm_supported_features(int F);
