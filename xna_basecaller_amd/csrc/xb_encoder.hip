@@ -1039,6 +1039,10 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
                                  // MFMAs -- measured on one box (profiles/r04_lstm_loop_ab.txt): no gain on top of XB_LSTM_DMA_ASM, a loss with one group per workgroup
 #define XB_LSTM_DMA_SPREAD 0
 #endif
+#ifndef XB_LSTM_DEFER_ARRIVE     // 1 (default): two groups per workgroup -- the arrival of a group-step is issued behind the first
+                                 // piece-closing drain + barrier of the OTHER group's step instead of behind a drain of its own (A/B builds: 0)
+#define XB_LSTM_DEFER_ARRIVE 1
+#endif
 #ifdef XB_NO_SIGNAL
 #define XB_SIG(x) false
 #else
@@ -1284,6 +1288,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
     }
     bool early = false;     // DUAL: the first piece of the coming group-step was requested during the previous one
+    // DUAL with both groups present: the exchange stores of a group-step are not drained at its end; the next full drain +
+    // barrier -- the one that closes the first piece of the other group's step, ~2.7 k cycles later -- covers them, and the
+    // arrival goes out behind that (the group's hand-off still has most of the other group's step to complete: its members
+    // are looked at ~3.8 k cycles after that point).  One group per slot: its next step waits for this very arrival -- not deferred.
+    constexpr bool DEFER = DUAL && XB_LSTM_DEFER_ARRIVE != 0;
+    unsigned *arrive_due = nullptr;
     int sig_i = 0, sig_next = XB_SIG(p.sig_flag) ? (int)((long long)T / p.sig_nts) : -1;     // slab being worked on, its end step
     for (int s = p.s_begin; s < p.s_end; ++s) {
         const int t = p.reverse ? T - 1 - s : s;
@@ -1511,6 +1521,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     if (DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
                     __syncthreads();
+                    if (DEFER && pc == 0 && arrive_due) {      // the other group's exchange stores are at L2 in every wave
+                        if (tid == 0) __hip_atomic_fetch_add(arrive_due, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        arrive_due = nullptr;
+                    }
                     XB_STAMP(7);   // piece DMA wait + barrier
                 }
                 if constexpr (I8) {
@@ -1536,6 +1550,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (s == 0) {      // no recurrent term in the very first step: the accumulators are the input projection
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if (DEFER && arrive_due) {
+                    if (tid == 0) __hip_atomic_fetch_add(arrive_due, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    arrive_due = nullptr;
+                }
                 acc_from_gin(acc);
             }
 
@@ -1677,12 +1695,23 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 // the staging are retired here)
                 __builtin_amdgcn_sched_barrier(0);
                 issue_gin(p.reverse ? T - 2 - s : s + 1);
+                if (DEFER && second) {
+                    // no drain here (see arrive_due); the barrier stays: the staging (and, YALT, piece buffer 1) is free for the
+                    // other group's step once every wave has read it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    arrive_due = cnt;
+                    XB_STAMP(5);
+                    XB_STAMP(6);
+                } else {
                 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 XB_STAMP(5);   // stores drained
                 if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 XB_STAMP(6);   // arrive
+                }
             } else {
                 __syncthreads();   // sT is rewritten next step (this also lands an early first piece)
             }
