@@ -240,8 +240,6 @@ def main():
     # three-product GEMMs read, xb_encoder.hip lstm_kernel)
     yalt = "true" if prec == _lib.XB_PREC_MIXED else "false"
     rec_kernel = "lstm_kernel<%d, %d, %s, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false", yalt)
-    if dual and F == 768 and prec in (_lib.XB_PREC_MIXED, _lib.XB_PREC_F16F8) and os.environ.get("XB_LSTM_QUAD", "0") not in ("", "0"):
-        rec_kernel = "lstm_quad_kernel<%s>" % yalt          # the opt-in software-pipelined experiment (csrc/xb_lstm_quad.h)
     roofline = {"kernel": rec_kernel,
                 "bound": "mfma",
                 "achieved": rec_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",

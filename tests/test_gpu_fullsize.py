@@ -83,9 +83,8 @@ def test_timed_workload_matches_serial_order_and_oracle(nb, N, monkeypatch):
     assert err < 2e-4, err
     # End to end (oracle encoder + oracle decode) is NOT asserted label for label: with seeded random weights at this
     # size the scores barely depend on the signal and the posteriors are nearly flat, so the 4e-5 score differences
-    # move a good part of the near-tied arg-max decisions (12 % at nb = 6).  What is exact is exact above.
-    lab2 = oracle.decode(ref, nb, SL, blank_score=2.0)["labels"]
-    assert (lab2 != lab).mean() < 0.5
+    # move a good part of the near-tied arg-max decisions (12 % at nb = 6).  What is exact is exact above; the end-to-end
+    # label comparison that means something is test_end_to_end_labels_on_the_peaky_model below.
 
 
 def test_slab_signalling_recurrence_equals_one_launch_per_slab(monkeypatch):

@@ -3,13 +3,24 @@ group-step between the MFMAs of the next) against lstm_kernel<48, 2, DUAL> (XB_L
 the other modules pin.  Same products in the same order, same gate arithmetic: every output must be BIT-identical -- scores,
 every layer's output planes, the called sequences -- for full and ragged group counts, several chunk slabs, time-slab
 launches, both second-part forms of the layer output (YALT) and both member placements."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 
 from conftest import encoder_shapes, seeded_state_dict
 from xna_basecaller_amd import _lib
 
 pytestmark = pytest.mark.gpu
+
+# Round 5: the kernel lives in the diagnostic library only (make -C xna_basecaller_amd/csrc diag; run this file with
+# XNA_LIBXNACALL=xna_basecaller_amd/libxnacall_diag.so python -m pytest tools/diag/test_gpu_lstm_quad.py); libxnacall.so
+# refuses XB_LSTM_QUAD.
+if "diag" not in os.environ.get("XNA_LIBXNACALL", ""):
+    pytest.skip("needs the diagnostic library (XNA_LIBXNACALL=.../libxnacall_diag.so)", allow_module_level=True)
 
 F, NB = 768, 5
 

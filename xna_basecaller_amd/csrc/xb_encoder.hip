@@ -1768,7 +1768,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     }
 }
 
-#include "xb_lstm_quad.h"
+#ifdef XB_WITH_QUAD          // the software-pipelined experiment: diagnostic library only (make diag), never libxnacall.so
+#include "../../tools/diag/xb_lstm_quad.h"
+#endif
 
 // dynamic LDS of lstm_kernel<KS, nsplit, dual>
 template <int KS>
@@ -1796,9 +1798,11 @@ template <int KS>
 hipError_t launch_lstm_ks(const xb::LstmParams &p, hipStream_t stream)
 {
     constexpr int F = KS * 16;
+#ifdef XB_WITH_QUAD
     if constexpr (KS == Q_KS) {
         if (p.quad) return launch_lstm_quad(p, stream);
     }
+#endif
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const bool dual = p.dual != 0;
     const int gh = dual ? (ngroups + 1) / 2 : ngroups;      // workgroup slots (lstm_kernel)
@@ -1971,7 +1975,11 @@ int lstm_resident_per_cu(int F, int nsplit, int dual)
     }
 }
 
+#ifdef XB_WITH_QUAD
 int lstm_quad_resident_per_cu() { return lstm_quad_occupancy(); }
+#else
+int lstm_quad_resident_per_cu() { return 0; }
+#endif
 int lstm_members(int F) { return F / LG_UNITS; }
 int lstm_group_chunks() { return LG_BN; }
 
@@ -1982,7 +1990,11 @@ hipError_t launch_lstm(const LstmParams &p, hipStream_t stream)
     if (p.n0 < 0 || p.n0 + p.nslab > p.N) return hipErrorInvalidValue;
     if (p.nsplit < 1 || p.nsplit > 5) return hipErrorInvalidValue;
     if (p.nsplit >= 4 && (!p.wq1 || !p.wq0 || !p.wscale)) return hipErrorInvalidValue;
+#ifdef XB_WITH_QUAD
     if (p.quad && (p.F != Q_F || p.nsplit != 2 || !p.persistent || !p.dual)) return hipErrorInvalidValue;
+#else
+    if (p.quad) return hipErrorInvalidValue;
+#endif
     if (p.sig_flag && (!p.persistent || p.s_begin != 0 || p.s_end != p.T || !p.sig_done || p.sig_nts < 1 || p.sig_nts > p.T))
         return hipErrorInvalidValue;
     switch (p.F / 16) {
