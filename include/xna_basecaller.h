@@ -16,17 +16,19 @@
  *     process, a CU mask) can keep part of them from becoming resident, in which case the waiting workgroups give up
  *     after a bounded spin and the next xb_synchronize / xb_collect_chunks reports XB_ERR_DEVICE.
  *   - the ctx owns its HIP streams (a main stream plus two low-priority side streams: the next
- *     layer's input GEMM runs beside the current layer's recurrence, the CRF decode of one batch beside the encoder
- *     of the next) and every device buffer it allocates.  A ctx is
+ *     layer's input GEMM runs beside the current layer's recurrence; the CRF decode of a batch runs on the MAIN stream
+ *     behind its encoder -- round 4's schedule; XB_DECODE_ASYNC=1 restores the side-stream decode beside the next batch's
+ *     encoder, the only case in which xb_result_stream is not the main stream) and every device buffer it allocates.  A ctx is
  *     used by one thread at a time (the reference calls compute_scores from ONE pipeline
  *     thread, crf/basecall.py:109-111); distinct ctxs are independent.
  *   - "host" entry points take host buffers owned by the caller and block until the result is
  *     in them.  "_dev" entry points take device pointers valid on the ctx's device (e.g.
  *     torch tensor data_ptr()), enqueue on the ctx's streams and return without waiting.  The ONLY completion
  *     point is xb_synchronize (it joins all of the ctx's streams): call it before reading results or reusing /
- *     freeing the buffers passed in.  Consecutive xb_basecall_chunks_dev calls pipeline (decode of batch k overlaps
- *     the encoder of batch k+1): give each in-flight batch its own d_seq / d_seq_len -- and its own d_signal that
- *     stays untouched until xb_synchronize (or until work ordered behind xb_result_stream has run).
+ *     freeing the buffers passed in.  Consecutive xb_basecall_chunks_dev calls queue up on the device back to back (no host
+ *     synchronisation between them; what runs concurrently is the co-scheduled pair below and, inside a batch, the next layer's
+ *     input GEMM beside the current recurrence): give each in-flight batch its own d_seq / d_seq_len -- and its own d_signal
+ *     that stays untouched until xb_synchronize (or until work ordered behind xb_result_stream has run).
  *   - a caller that keeps two batches in flight can have them CO-SCHEDULED: after xb_reserve_pairing (an explicit opt-in;
  *     contexts of at most 512 chunks; XB_FUSE=0 refuses) an xb_basecall_chunks_dev / xb_submit_chunks that finds nothing
  *     held back is itself held back (NOTHING is enqueued yet -- a device-wide synchronise or an event recorded on a stream
@@ -264,14 +266,21 @@ XB_API void *xb_result_stream(xb_ctx *ctx);
  *   xb_comm_fence       makes the streams of ctx wait (on the device) for the gather issued `lag` calls ago (0: the latest, 1: the
  *                       one before it) and everything older -- call it before output buffers a gather still reads are handed
  *                       to a later xb_basecall_chunks_dev (two buffer sets in rotation: lag 1 right before enqueueing a batch);
- *   xb_comm_synchronize host-side completion of the gathers issued so far.
+ *   xb_comm_synchronize host-side completion of the gathers asked for so far (one still waiting for a held-back basecall is
+ *                       launched first).
  */
 #define XB_COMM_ID_BYTES 128
 typedef struct xb_comm xb_comm;
 XB_API int xb_comm_unique_id(char id[XB_COMM_ID_BYTES]);
 XB_API int xb_comm_create(xb_comm **out, int device, int rank, int world, const char id[XB_COMM_ID_BYTES]);
-/* xb_comm_destroy: after xb_synchronize of every context the communicator gathered for (a gather can be waiting for a
- * held-back basecall of that context, see the header comment on co-scheduling). */
+/* xb_comm_destroy: DESTROY ORDER -- the communicator first or the contexts first, both are safe, under one rule: every
+ * context it gathered for and every buffer handed to xb_gather_called must still be alive when xb_comm_destroy is called if a
+ * gather is still waiting for a held-back basecall of that context (see the header comment on co-scheduling).
+ * xb_comm_destroy and xb_comm_synchronize launch such a basecall themselves (as xb_result_stream(ctx) would) and wait for
+ * its gather, so no deferred gather outlives its communicator; after xb_comm_destroy the context holds no reference to it.
+ * Destroying the context first launches the held call too (xb_ctx_destroy), with the communicator still alive.  What is NOT
+ * allowed: freeing d_seq / d_seq_len / d_all_* of a batch before xb_synchronize(ctx) (or xb_comm_synchronize for the
+ * gathered rows) has returned -- a held call writes them when it is launched. */
 XB_API void xb_comm_destroy(xb_comm *comm);
 XB_API int xb_comm_rank(const xb_comm *comm);
 XB_API int xb_comm_world(const xb_comm *comm);

@@ -38,7 +38,12 @@ def load_reference():
         _placeholder(name)
     _placeholder("pysam", AlignmentFile=object, AlignmentHeader=object, AlignedSegment=object)
     _placeholder("ont_fast5_api.fast5_interface", get_fast5_file=None)
-    _placeholder("mappy", __version__="2.23")
+    # mappy.revcomp is the one mappy FUNCTION the aligned branch of sam_record calls (io.py:133).  mappy is in no image; the
+    # stand-in below restates minimap2's complement table (sketch.c seq_comp_table: the IUPAC codes, both cases, every
+    # other byte unchanged) -- so the XNA letter X stays X while Y, an IUPAC code, becomes R.  Flagged in sam.json.
+    comp = {a: b for a, b in zip("ACGTUMRWSYKVHDBN", "TGCAAKYWSRMBDHVN")}
+    comp.update({a.lower(): b.lower() for a, b in list(comp.items())})
+    _placeholder("mappy", __version__="2.23", revcomp=lambda seq: "".join(comp.get(c, c) for c in reversed(seq)))
     pkg = _placeholder("bonito", __version__=version)
     pkg.__path__ = []
     _placeholder("bonito.cli")
@@ -82,7 +87,26 @@ def main():
         records.append({"read": r, "sequence": s, "qstring": q, "tags": full,
                         "sam_record": rio.sam_record(r["read_id"], s, q, False, tags=full),
                         "sam_record_no_tags": rio.sam_record(r["read_id"], s, q, False)})
-    out = {"note": "strings returned by the reference's sam_header / sam_record (unaligned) / Read.readgroup / Read.tagdata",
+    # ---- aligned records (io.py:118-137): the reference's sam_record with a stand-in for the mappy.Alignment object -- the
+    # attributes it reads: ctg, r_st, q_st, q_en, strand, mapq, cigar_str, NM, MD.  Both strands, soft clips at neither /
+    # one / both ends, with and without tags.
+    aligned = []
+    cases = [dict(ctg="POC_T1", r_st=0, r_en=10, q_st=0, q_en=10, strand=1, mapq=60, cigar_str="10M", NM=0, MD="10"),
+             dict(ctg="POC_T1", r_st=3, r_en=12, q_st=2, q_en=11, strand=1, mapq=37, cigar_str="4M1I4M", NM=2, MD="3A4"),
+             dict(ctg="POC_T2", r_st=5, r_en=13, q_st=0, q_en=8, strand=-1, mapq=12, cigar_str="3M1D5M", NM=1, MD="3^C5"),
+             dict(ctg="CPLX_7", r_st=100, r_en=112, q_st=1, q_en=13, strand=-1, mapq=0, cigar_str="12M", NM=3, MD="2T4G3A0"),
+             dict(ctg="POC_T3", r_st=41, r_en=42, q_st=0, q_en=1, strand=-1, mapq=1, cigar_str="1M", NM=0, MD="1")]
+    aseqs = ["ACGTXYACGT", "GGGTTTAXAYA", "ACGTXAYT", "ACGTACGTACGTXXYY", "T"]
+    aquals = ["%&'()*+,-.", "OOOOOOOOOOO", "12345678", "5555566666777788", "I"]
+    for i, (m, s, q) in enumerate(zip(cases, aseqs, aquals)):
+        tags = ["RG:Z:run00_%s" % model, "qs:i:%d" % (9 + i)]
+        mp = types.SimpleNamespace(**m)
+        aligned.append({"read_id": "aligned-%d" % i, "sequence": s, "qstring": q, "mapping": m, "tags": tags,
+                        "sam_record": rio.sam_record("aligned-%d" % i, s, q, mp, tags=tags),
+                        "sam_record_no_tags": rio.sam_record("aligned-%d" % i, s, q, mp)})
+    out = {"note": "strings returned by the reference's sam_header / sam_record (unaligned, and aligned with a stand-in mapping "
+                   "object and a stand-in for mappy.revcomp restating minimap2's complement table) / Read.readgroup / Read.tagdata",
+           "aligned": aligned,
            "bonito_version": version, "mappy_version": "2.23", "model": model, "argv": argv, "linesep": os.linesep,
            "groups": groups, "header": header, "records": records}
     with open(os.path.join(HERE, "sam.json"), "w") as fh:

@@ -358,7 +358,7 @@ def test_read_loader_lookahead_is_bounded(tmp_path):
         time.sleep(0.01)                                   # a slow device stage
         got.append(r.read_id)
     assert got == serial and 1 <= loader.max_pending <= 5
-    assert xreads.ReadLoader(str(tmp_path), n_proc=2).lookahead == 8
+    assert xreads.ReadLoader(str(tmp_path), n_proc=2).lookahead == 64
 
 
 def test_env_rank_world(monkeypatch):
@@ -721,8 +721,16 @@ def test_sam_text_output_matches_the_reference_functions(tmp_path):
     # without an aligner (the only case here) the aligner's @PG line is not claimed; everything else is unchanged
     plain = xio.sam_header(groups, version=g["bonito_version"], argv=g["argv"])
     assert plain == "".join(l for l in g["header"].splitlines(True) if not l.startswith("@PG\tID:aligner"))
-    with pytest.raises(NotImplementedError):
-        xio.sam_record("r", "ACGT", "IIII", mapping=object())
+    # aligned records (io.py:118-137), round 5: the reference's sam_record driven with a stand-in mapping object, both
+    # strands, soft clips at neither / one / both ends; mappy.revcomp restated (X stays X, the IUPAC code Y becomes R)
+    assert len(g["aligned"]) >= 5 and {a["mapping"]["strand"] for a in g["aligned"]} == {1, -1}
+    for a in g["aligned"]:
+        m = types.SimpleNamespace(**a["mapping"])
+        assert xio.sam_record(a["read_id"], a["sequence"], a["qstring"], m, tags=a["tags"]) == a["sam_record"]
+        assert xio.sam_record(a["read_id"], a["sequence"], a["qstring"], m) == a["sam_record_no_tags"]
+        f = a["sam_record"].split("\t")
+        assert f[1] == ("0" if m.strand == 1 else "16") and int(f[3]) == m.r_st + 1 and len(f[9]) == len(f[10])
+    assert xio.revcomp("ACGTXYacgtN") == "NacgtRXACGT" and xio.revcomp("") == ""
     # the writer: header first, then the records in order, an empty call skipped, summary rows as for FASTQ
     out = pyio.StringIO()
     results = [(r, {"sequence": rec["sequence"], "qstring": rec["qstring"], "mean_qscore": float(rec["tags"][1].split(":")[2])})

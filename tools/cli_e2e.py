@@ -5,6 +5,9 @@ writes a model directory (shipped geometry: features 768, 6-base CRF, seeded wei
 signal bundle of READS reads x ~SAMPLES raw samples under /tmp, runs `python -m xna_basecaller_amd basecaller` with
 stdout redirected to a .fastq file and reports the CLI's own "> samples per second" (cli/basecaller.py:153-161).
 Usage: python tools/cli_e2e.py [--reads 2000] [--samples 50000] [--batch 512]
+Round 5: --container fast5 writes multi-read fast5 files (tests/h5write.py: classic HDF5 layout, VBZ) instead of bundles and
+--per-file sets the reads per container: the reference's real read shapes are POC ~3 000 samples (ONE left-padded chunk per
+read, 4 000 reads per file) and CPLX ~25 000 samples (VERDICT r4 next 2 -> profiles/r05_cli_e2e_shapes.txt).
 """
 import argparse
 import os
@@ -28,6 +31,9 @@ def main():
     ap.add_argument("--chunksize", type=int, default=10000)
     ap.add_argument("--features", type=int, default=768)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--container", choices=("npz", "fast5"), default="npz")
+    ap.add_argument("--per-file", type=int, default=250)
+    ap.add_argument("--spread", type=float, default=0.4, help="read lengths are samples * U(1 - spread, 1 + spread)")
     ap.add_argument("--fuse", default="", help="comma list of XB_FUSE values to run the CLI under, on the same reads (e.g. 1,0)")
     args = ap.parse_args()
     import torch
@@ -51,11 +57,14 @@ def main():
 
     rng = np.random.default_rng(3)
     t0 = time.time()
-    per_file = 250
+    per_file = args.per_file
+    if args.container == "fast5":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from h5write import write_multi_fast5
     for f0 in range(0, args.reads, per_file):
         recs = []
         for i in range(f0, min(f0 + per_file, args.reads)):
-            length = int(args.samples * rng.uniform(0.6, 1.4))
+            length = int(args.samples * rng.uniform(1.0 - args.spread, 1.0 + args.spread))
             base = rng.normal(90.0, 12.0, length)
             lead = int(rng.integers(300, 900))
             base[:lead] = rng.normal(140.0, 3.0, lead)
@@ -64,8 +73,11 @@ def main():
                                    sampling_rate=4000.0, run_id="runX", channel_number=str(1 + i % 512),
                                    start_mux=1 + i % 4, read_number=i, start_time=4000 * i, duration=length,
                                    exp_start_time="2021-06-01T10:00:00Z")))
-        xreads.write_bundle(os.path.join(reads_dir, "batch%04d.xsig.npz" % (f0 // per_file)), recs)
-    print("wrote %d reads in %.1f s" % (args.reads, time.time() - t0), flush=True)
+        if args.container == "fast5":
+            write_multi_fast5(os.path.join(reads_dir, "batch%04d.fast5" % (f0 // per_file)), recs, vbz=True)
+        else:
+            xreads.write_bundle(os.path.join(reads_dir, "batch%04d.xsig.npz" % (f0 // per_file)), recs)
+    print("wrote %d reads (%s, %d per file) in %.1f s" % (args.reads, args.container, per_file, time.time() - t0), flush=True)
 
     out = os.path.join(work, "calls.fastq")
     rc, digests = 0, []
@@ -79,7 +91,8 @@ def main():
                                stdout=fh, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t0
         err = r.stderr.decode()
-        print("== XB_FUSE=%s (reads %d x ~%d samples, batch %d)" % (fuse, args.reads, args.samples, args.batch))
+        print("== XB_FUSE=%s (reads %d x ~%d samples, %s, %d per file, batch %d)"
+              % (fuse, args.reads, args.samples, args.container, per_file, args.batch))
         print("\n".join(l for l in err.splitlines() if l.startswith(">") and "model basecaller params" not in l)[-1500:])
         import hashlib
         digests.append(hashlib.sha1(open(out, "rb").read()).hexdigest())

@@ -29,6 +29,8 @@ EXPORTS = [
     "xb_beam_search", "xb_beam_search_dev", "xb_basecall_chunks_beam", "xb_reserve_pairing", "xb_pairing_active", "xb_debug_layer_output",
 ]
 XB_COMM_ID_BYTES = 128
+# xb_status (include/xna_basecaller.h)
+XB_OK, XB_ERR_INVALID, XB_ERR_HIP, XB_ERR_NOMEM, XB_ERR_STATE, XB_ERR_DEVICE, XB_ERR_NO_GPU = 0, -1, -2, -3, -4, -5, -6
 XB_PIPELINE_SLOTS = 4          # include/xna_basecaller.h
 
 

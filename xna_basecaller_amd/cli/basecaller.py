@@ -86,6 +86,19 @@ def _gathered_results(results, loader, rank, world, window=256):
         raise failure
 
 
+def reader_procs(world=1):
+    """Reader workers of this rank: the reference's 8 (cli/basecaller.py:107-111) when the host has them to give -- the cores
+    this process may run on, divided by the ranks that share the node (LOCAL_WORLD_SIZE under torchrun, else the world size),
+    one core per rank left for its own pipeline threads; XB_READER_PROCS overrides.  8 ranks x 8 workers on a 64-core node
+    would otherwise put 72 busy processes on 64 cores and slow every rank's reader (host budget)."""
+    env = os.environ.get("XB_READER_PROCS", "")
+    if env:
+        return max(1, int(env))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world) or 1))
+    return max(1, min(8, cores // local - 1))
+
+
 def main(args):
     if args.read_ids is not None and not os.path.isfile(args.read_ids):
         raise FileNotFoundError(args.read_ids)
@@ -94,7 +107,8 @@ def main(args):
     # initialises HIP and starts runtime threads) is only joined once the pool exists.  Under torchrun every rank only
     # ever loads its own shard of the reads.
     rank, world = xdist.env_rank_world()
-    reads = get_reads(args.reads_directory, n_proc=8, recursive=args.recursive,
+    n_proc = reader_procs(world)
+    reads = get_reads(args.reads_directory, n_proc=n_proc, recursive=args.recursive,
                       read_ids=column_to_set(args.read_ids), skip=args.skip, limit=args.max_reads,
                       shard=(rank, world) if world > 1 else None)
     rank, world = xdist.init_from_env()
@@ -133,7 +147,7 @@ def main(args):
     groups = []
     if fmt.name != "fastq" and rank == 0:
         groups = get_read_groups(args.reads_directory, args.model_directory, recursive=args.recursive,
-                                 read_ids=column_to_set(args.read_ids), skip=args.skip)
+                                 read_ids=column_to_set(args.read_ids), skip=args.skip, n_proc=n_proc)
 
     results = basecall(model, reads, reverse=args.revcomp,
                        batchsize=model.config["basecaller"]["batchsize"],
@@ -164,6 +178,7 @@ def main(args):
         # (the reference's metric above counts READ samples); tools/cli_e2e.py compares this rate with bench.py's
         chunks = getattr(model, "chunks_submitted", 0)
         sys.stderr.write("> duration (s): %.2f\n" % duration)
+        sys.stderr.write("> reads per second: %.0f (reader workers: %d)\n" % (len(writer.log) / duration, n_proc))
         sys.stderr.write("> chunks basecalled: %d x %d samples = %.3E chunk samples per second\n"
                          % (chunks, model.config["basecaller"]["chunksize"], chunks * model.config["basecaller"]["chunksize"] / duration))
     sys.stderr.write("> done\n")

@@ -10,6 +10,7 @@ reference so that util.load_model/match_names work unchanged).  No torch op runs
 decode: both call the hand-written HIP kernels through the C ABI (include/xna_basecaller.h).
 """
 import os
+import sys
 import weakref
 
 import numpy as np
@@ -433,8 +434,10 @@ class Model(torch.nn.Module):
             ctx._pairing_asked = True
             try:
                 ctx.reserve_pairing()
-            except _lib.XbError:            # no room for a pair (XB_ERR_NOMEM): the context carries on unpaired
-                pass
+            except _lib.XbError as e:
+                if e.code != _lib.XB_ERR_NOMEM:     # a device / HIP failure inside the reservation is NOT "no room": surface it
+                    raise
+                sys.stderr.write("> no device memory for co-scheduled pairs of %d chunks: every call runs on its own\n" % n)
         return 4 if ctx.pairing_active() else 2
 
     @staticmethod

@@ -74,6 +74,9 @@ struct xb_comm {
     hipEvent_t ready = nullptr, done[2] = {};       // producer -> gather; gather -> producer (the last two gathers)
     unsigned issued = 0;          // gathers enqueued on the stream so far
     unsigned queued = 0;          // gathers asked for so far (a gather can wait for a held-back basecall: xb_gather_called)
+    xb_ctx *waiting_on = nullptr; // the context whose held-back basecall carries this communicator's deferred gather (queued >
+                                  // issued): xb_comm_synchronize / xb_comm_destroy launch that call first, so that no deferred
+                                  // gather ever outlives its communicator
     int failed_rc = 0;            // a collective of this communicator failed (or could not be enqueued): STICKY.  The other ranks
                                   // have entered, or will enter, that all-gather; skipping it here and carrying on would leave
                                   // them blocked in it.  Every later gather / fence / synchronize fails with this code and the
@@ -133,10 +136,20 @@ XB_API int xb_comm_create(xb_comm **out, int device, int rank, int world, const 
     return XB_OK;
 }
 
+namespace {
+// a gather deferred behind a held-back basecall (xb_gather_called): launch that call now -- its gather runs right behind it
+void flush_deferred(xb_comm *c)
+{
+    if (c->queued != c->issued && c->waiting_on) (void)xb_result_stream(c->waiting_on);
+    c->waiting_on = nullptr;
+}
+}  // namespace
+
 XB_API void xb_comm_destroy(xb_comm *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    flush_deferred(c);            // the caller's buffers and the context of a deferred gather must still be alive here (header)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     if (c->ready) (void)hipEventDestroy(c->ready);
@@ -160,6 +173,7 @@ int gather_now(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const int32_t *d_se
 void gather_later(void *p)
 {
     GatherArgs *g = static_cast<GatherArgs *>(p);
+    g->c->waiting_on = nullptr;
     const int rc = gather_now(g->c, g->ctx, g->d_seq, g->d_len, g->n, g->T, g->all_seq, g->all_len);
     (void)rc;                                       // a failure is sticky in the communicator: the next call reports it
     delete g;
@@ -176,7 +190,7 @@ XB_API int xb_gather_called(xb_comm *c, xb_ctx *ctx, const int8_t *d_seq, const 
         // the basecall that writes d_seq may be held back to share a pass with the next one (xb_basecall_chunks_dev): the gather
         // is then enqueued right behind its launch, in the order of the xb_gather_called calls
         GatherArgs *g = new GatherArgs{c, ctx, d_seq, d_seq_len, n, T, d_all_seq, d_all_len};
-        if (xb_internal_defer_after(ctx, d_seq, &gather_later, g)) { c->queued += 1; return XB_OK; }
+        if (xb_internal_defer_after(ctx, d_seq, &gather_later, g)) { c->queued += 1; c->waiting_on = ctx; return XB_OK; }
         delete g;
         if (c->queued != c->issued) (void)xb_result_stream(ctx);     // an older gather is still waiting for its basecall: launch it first
     }
@@ -230,6 +244,7 @@ XB_API int xb_comm_synchronize(xb_comm *c)
 {
     if (!c) return XB_ERR_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return cfail(c, XB_ERR_HIP, "hipSetDevice failed");
+    flush_deferred(c);            // "every gather asked for so far is complete" includes one still waiting for its basecall
     if (hipStreamSynchronize(c->stream) != hipSuccess) return cfail(c, XB_ERR_HIP, "gather stream failed");
     return c->failed_rc;            // XB_OK, or the sticky failure of an earlier (possibly deferred) gather
 }

@@ -29,6 +29,8 @@ a MinKNOW file.  zstd itself comes from the system's libzstd through ctypes.
 """
 import ctypes
 import ctypes.util
+import mmap
+import os
 import struct
 import zlib
 
@@ -53,8 +55,10 @@ _zstd = None
 def _libzstd():
     global _zstd
     if _zstd is None:
-        name = ctypes.util.find_library("zstd") or "libzstd.so.1"
-        lib = ctypes.CDLL(name)
+        try:                                                # the soname first: find_library runs ldconfig / gcc (0.1-1 s)
+            lib = ctypes.CDLL("libzstd.so.1")
+        except OSError:
+            lib = ctypes.CDLL(ctypes.util.find_library("zstd") or "libzstd.so")
         lib.ZSTD_decompress.restype = ctypes.c_size_t
         lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
         lib.ZSTD_compress.restype = ctypes.c_size_t
@@ -69,16 +73,25 @@ def _libzstd():
     return _zstd
 
 
+def preload():
+    """Resolve the lazily loaded pieces NOW (a reader pool calls this before it forks, so that no worker pays for them)."""
+    try:
+        _libzstd()
+    except OSError:
+        pass                                                # no libzstd: only VBZ chunks need it, and they will say so
+
+
 def zstd_decompress(data, max_out):
+    """One zstd frame -> its bytes (a uint8 array view of the output buffer: no copy on the way out)."""
     lib = _libzstd()
     src = bytes(data)
     known = lib.ZSTD_getFrameContentSize(src, len(src))
     cap = int(known) if known < (1 << 62) else int(max_out)
-    out = ctypes.create_string_buffer(max(cap, 1))
-    n = lib.ZSTD_decompress(out, cap, src, len(src))
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n = lib.ZSTD_decompress(out.ctypes.data, cap, src, len(src))
     if lib.ZSTD_isError(n):
         raise Hdf5Error("zstd: corrupt frame")
-    return out.raw[:n]
+    return out[:n]
 
 
 def zstd_compress(data, level=1):
@@ -95,14 +108,19 @@ def zstd_compress(data, level=1):
 def _svb16_decode(buf, count):
     """count 16-bit values: key bits (1 per value, LSB first) then 1- or 2-byte little-endian data."""
     nkey = (count + 7) // 8
-    keys = np.unpackbits(np.frombuffer(buf, dtype=np.uint8, count=nkey), bitorder="little")[:count].astype(np.int64)
+    if len(buf) < nkey:
+        raise Hdf5Error("vbz: truncated svb16 keys")
+    two = np.unpackbits(np.frombuffer(buf, dtype=np.uint8, count=nkey), bitorder="little")[:count].view(np.bool_)
     data = np.frombuffer(buf, dtype=np.uint8, offset=nkey)
-    starts = np.concatenate(([0], np.cumsum(1 + keys)[:-1])) if count else np.zeros(0, np.int64)
-    if count and starts[-1] + 1 + keys[-1] > data.size:
+    # the stream is value after value, low byte first: exactly the row-major order of the (count, 2) byte matrix
+    take = np.ones((count, 2), dtype=np.bool_)
+    take[:, 1] = two
+    total = count + int(np.count_nonzero(two))
+    if total > data.size:
         raise Hdf5Error("vbz: truncated svb16 stream")
-    lo = data[starts].astype(np.uint16)
-    hi = np.where(keys == 1, data[np.minimum(starts + 1, data.size - 1)], 0).astype(np.uint16)
-    return lo | (hi << 8)
+    out = np.zeros((count, 2), dtype=np.uint8)
+    out[take] = data[:total]
+    return out.view("<u2").reshape(count)
 
 
 def _svb32_decode(buf, count, lengths=(1, 2, 3, 4)):
@@ -112,42 +130,44 @@ def _svb32_decode(buf, count, lengths=(1, 2, 3, 4)):
     if len(buf) < nkey:
         raise Hdf5Error("vbz: truncated StreamVByte keys")
     kb = np.frombuffer(buf, dtype=np.uint8, count=nkey)
-    codes = np.stack([(kb >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)[:count].astype(np.int64)
-    nbytes = np.asarray(lengths, dtype=np.int64)[codes]
+    codes = np.empty((nkey, 4), dtype=np.uint8)
+    for i, sh in enumerate((0, 2, 4, 6)):
+        codes[:, i] = (kb >> sh) & 3
+    nbytes = np.asarray(lengths, dtype=np.uint8)[codes.reshape(-1)[:count]]
     data = np.frombuffer(buf, dtype=np.uint8, offset=nkey)
-    starts = np.concatenate(([0], np.cumsum(nbytes)[:-1])) if count else np.zeros(0, np.int64)
-    if count and starts[-1] + nbytes[-1] > data.size:
+    # the stream is value after value, low byte first: exactly the row-major order of the (count, 4) byte matrix, so
+    # ONE boolean-mask assignment places every data byte
+    take = np.arange(4, dtype=np.uint8)[None, :] < nbytes[:, None]
+    total = int(nbytes.sum(dtype=np.int64))
+    if total > data.size:
         raise Hdf5Error("vbz: truncated StreamVByte data")
-    out = np.zeros(count, dtype=np.uint32)
-    for b in range(4):
-        take = nbytes > b
-        idx = np.minimum(starts + b, max(data.size - 1, 0))
-        out |= np.where(take, data[idx].astype(np.uint32) << (8 * b), 0).astype(np.uint32)
-    return out
+    out = np.zeros((count, 4), dtype=np.uint8)
+    out[take] = data[:total]
+    return out.view("<u4").reshape(count)
 
 
 def _unzigzag_cumsum(v, dtype):
     """zig-zag codes of differences -> samples, in `dtype`'s modular arithmetic"""
-    v = v.astype(dtype)
-    v = ((v >> 1) ^ (0 - (v & 1))).astype(dtype)
-    return np.cumsum(v, dtype=dtype)
+    v = v.astype(dtype, copy=False)
+    one = dtype(1)
+    return np.cumsum((v >> one) ^ (dtype(0) - (v & one)), dtype=dtype)
 
 
 def vbz_decode(chunk, cd_values):
-    """One VBZ-filtered chunk -> raw little-endian sample bytes."""
+    """One VBZ-filtered chunk -> the raw little-endian samples (bytes, or an array of the sample type: a buffer either way)."""
     version, int_size, zigzag, level = (list(cd_values) + [0, 0, 0, 0])[:4]
     if version not in (0, 1):
         raise Hdf5Error("vbz: unsupported version %d" % version)
     if len(chunk) < 4:
         raise Hdf5Error("vbz: short chunk")
     (size,) = struct.unpack_from("<I", chunk, 0)
-    body = bytes(chunk[4:])
+    body = chunk[4:]
     if level:
         body = zstd_decompress(body, 5 * size // max(int_size, 1) + size + 64)
     if int_size == 0 or (int_size == 1 and version == 1):
         if len(body) < size:
             raise Hdf5Error("vbz: short chunk")
-        return body[:size]
+        return bytes(body[:size])
     if int_size not in (1, 2, 4):
         raise Hdf5Error("vbz: unsupported integer size %d" % int_size)
     count = size // int_size
@@ -157,16 +177,16 @@ def vbz_decode(chunk, cd_values):
         v = _svb32_decode(body, count)
         if zigzag:
             v = _unzigzag_cumsum(v, np.uint32)
-        return v.astype(out_dtype).tobytes()
+        return v.astype(out_dtype)
     if int_size == 2:
         v = _svb16_decode(body, count)
         if zigzag:
             v = _unzigzag_cumsum(v, np.uint16)
-        return v.astype(out_dtype).tobytes()
+        return v.astype(out_dtype)
     v = _svb32_decode(body, count, lengths=(0, 1, 2, 4))
     if zigzag:
         v = _unzigzag_cumsum(v, np.uint32)
-    return v.astype(out_dtype).tobytes()
+    return v.astype(out_dtype)
 
 
 def _svb16_encode(values):
@@ -222,6 +242,11 @@ def vbz_encode_int16(samples, level=1, version=0):
 # ---------------------------------------------------------------------------------------------------------------
 # low-level reader
 # ---------------------------------------------------------------------------------------------------------------
+_HHB = struct.Struct("<HHB").unpack_from
+_ATTR = struct.Struct("<BxHHH").unpack_from
+_DTYPE = struct.Struct("<B3sI").unpack_from
+
+
 class _Buf:
     def __init__(self, data, offset_size=8, length_size=8):
         self.d, self.O, self.L = data, offset_size, length_size
@@ -240,10 +265,9 @@ class _Datatype:
     """Decoded datatype message (class, element size, numpy dtype or string / vlen description)."""
 
     def __init__(self, buf, pos):
-        b0 = buf.u(pos, 1)
+        b0, bits, self.size = _DTYPE(buf.d, pos)
         self.cls, self.version = b0 & 0x0F, b0 >> 4
-        bits = buf.u(pos + 1, 3)
-        self.size = buf.u(pos + 4, 4)
+        bits = int.from_bytes(bits, "little")
         self.np = None
         self.vlen_string = False
         self.base = None
@@ -288,19 +312,26 @@ def _dataspace(buf, pos):
 class File:
     """
     with File(path) as f:  f["read_<id>/Raw/Signal"][:] ;  f["read_<id>/Raw"].attrs["start_time"] ;  f.keys()
-    The whole file is memory-mapped; nothing is written.
+    The whole file is memory-mapped (a plain `mmap`: slices are `bytes`, integers come from `int.from_bytes`, names from
+    `find(b"\0")` -- no numpy scalar indexing on the metadata path); nothing is written.  A group's links are enumerated once
+    and kept (`Group._links`), and the root group lives as long as the File: looking a read up in an open multi-read file is
+    one dict access (`object_at` skips even that when the caller kept the address from an earlier enumeration).
     """
 
     def __init__(self, path, mode="r"):
         if mode != "r":
             raise Hdf5Error("hdf5_lite is read-only")
         self.path = str(path)
-        self._mm = np.memmap(self.path, dtype=np.uint8, mode="r")
+        with open(self.path, "rb") as fh:
+            if os.fstat(fh.fileno()).st_size < 8:
+                raise Hdf5Error("%s is not an HDF5 file" % self.path)
+            self._mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
         data = self._mm
         base = 0
-        while bytes(data[base:base + 8]) != SIGNATURE:       # the superblock may sit at 0, 512, 1024, ...
+        while data[base:base + 8] != SIGNATURE:              # the superblock may sit at 0, 512, 1024, ...
             base = 512 if base == 0 else base * 2
-            if base + 8 > data.size:
+            if base + 8 > len(data):
+                self._mm.close()
                 raise Hdf5Error("%s is not an HDF5 file" % self.path)
         ver = int(data[base + 8])
         if ver in (0, 1):
@@ -318,6 +349,7 @@ class File:
         else:
             raise Hdf5Error("superblock version %d not supported" % ver)
         self._gheap = {}
+        self._attr_memo = {}
         self.root = Group(self, root_header + self.base_address, "/")
 
     # --- group protocol on the root --------------------------------------------------------------------------
@@ -334,9 +366,19 @@ class File:
     def attrs(self):
         return self.root.attrs
 
+    def object_at(self, addr, name=""):
+        """The group or dataset whose object header sits at absolute address `addr` (as enumerated by `Group.links()`)."""
+        return _typed(_Object(self, addr, name))
+
     def close(self):
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:                              # a caller still holds a view: let the collector unmap it
+                pass
         self._mm = None
         self.buf = None
+        self.root = None
 
     def __enter__(self):
         return self
@@ -387,8 +429,9 @@ class _Object:
         while blocks and remaining > 0:
             p, size = blocks.pop(0)
             end = p + size
+            d = buf.d
             while p + 8 <= end and remaining > 0:
-                mtype, msize, mflags = buf.u(p, 2), buf.u(p + 2, 2), buf.u(p + 4, 1)
+                mtype, msize, mflags = _HHB(d, p)
                 body = p + 8
                 remaining -= 1
                 if mtype == 0x0010:                         # continuation
@@ -443,25 +486,35 @@ class _Object:
 
     def _attribute(self, pos):
         buf = self.file.buf
-        ver = buf.u(pos, 1)
-        nsz, tsz, ssz = buf.u(pos + 2, 2), buf.u(pos + 4, 2), buf.u(pos + 6, 2)
+        ver, nsz, tsz, ssz = _ATTR(buf.d, pos)
         p = pos + 8 + (1 if ver == 3 else 0)
-        pad = (lambda n: (n + 7) & ~7) if ver == 1 else (lambda n: n)
-        name = bytes(buf.d[p:p + nsz]).split(b"\0")[0].decode("utf-8", "replace")
-        p += pad(nsz)
-        dt = _Datatype(buf, p)
-        p += pad(tsz)
-        shape = _dataspace(buf, p)
-        p += pad(ssz)
-        count = int(np.prod(shape)) if shape else (1 if shape == () else 0)
-        return name, self.file_value(dt, p, count, shape)
+        if ver == 1:
+            nsz8, tsz8, ssz8 = (nsz + 7) & ~7, (tsz + 7) & ~7, (ssz + 7) & ~7
+        else:
+            nsz8, tsz8, ssz8 = nsz, tsz, ssz
+        # name, datatype and dataspace of an attribute are the same bytes in every read group of a fast5 file (only the value
+        # behind them differs): decode each distinct description once per file
+        head = buf.d[pos:p + nsz8 + tsz8 + ssz8]
+        memo = self.file._attr_memo
+        hit = memo.get(head)
+        if hit is None:
+            name = buf.d[p:p + nsz].split(b"\0", 1)[0].decode("utf-8", "replace")
+            dt = _Datatype(_Buf(head, buf.O, buf.L), p - pos + nsz8)
+            shape = _dataspace(_Buf(head, buf.O, buf.L), p - pos + nsz8 + tsz8)
+            count = int(np.prod(shape)) if shape else (1 if shape == () else 0)
+            hit = memo[head] = (name, dt, shape, count)
+            if len(memo) > 4096:
+                memo.clear()
+        name, dt, shape, count = hit
+        return name, self.file_value(dt, p + nsz8 + tsz8 + ssz8, count, shape)
 
     def file_value(self, dt, p, count, shape):
         buf = self.file.buf
         if dt.np is not None:
-            a = np.frombuffer(bytes(buf.d[p:p + count * dt.size]), dtype=dt.np, count=count)
-            a = a.astype(a.dtype.newbyteorder("="))
-            return a[0].item() if shape == () else a.reshape(shape)
+            a = np.frombuffer(buf.d[p:p + count * dt.size], dtype=dt.np, count=count)
+            if shape == ():
+                return a[0].item()
+            return a.astype(a.dtype.newbyteorder("=")).reshape(shape)
         if dt.cls == 3:
             vals = [bytes(buf.d[p + i * dt.size:p + (i + 1) * dt.size]).split(b"\0")[0].rstrip(b" ") if dt.pad == 2 else
                     bytes(buf.d[p + i * dt.size:p + (i + 1) * dt.size]).split(b"\0")[0] for i in range(count)]
@@ -496,12 +549,11 @@ class Group(_Object):
                 raise Hdf5Error("bad local heap")
             heap_data = buf.off(heap + 8 + 2 * buf.L) + f.base_address
 
+            d = buf.d
+
             def name_at(off):
                 q = heap_data + off
-                end = q
-                while buf.d[end] != 0:
-                    end += 1
-                return bytes(buf.d[q:end]).decode("utf-8", "replace")
+                return d[q:d.find(b"\0", q)].decode("utf-8", "replace")
 
             def walk(node):
                 sig = bytes(buf.d[node:node + 4])
@@ -554,6 +606,10 @@ class Group(_Object):
     def keys(self):
         return list(self._links().keys())
 
+    def links(self):
+        """{child name: absolute object-header address} (File.object_at opens one without another lookup)"""
+        return self._links()
+
     def __contains__(self, name):
         try:
             self[name]
@@ -571,13 +627,13 @@ class Group(_Object):
                 raise KeyError(name)
             addr = links[part]
             child_name = (node.name.rstrip("/") + "/" + part)
-            obj = _Object(self.file, addr, child_name)
-            if obj.find(0x0008) or obj.find(0x0001) and obj.find(0x0003):
-                obj.__class__ = Dataset
-            else:
-                obj.__class__ = Group
-            node = obj
+            node = _typed(_Object(self.file, addr, child_name))
         return node
+
+
+def _typed(obj):
+    obj.__class__ = Dataset if (obj.find(0x0008) or obj.find(0x0001) and obj.find(0x0003)) else Group
+    return obj
 
 
 class Dataset(_Object):

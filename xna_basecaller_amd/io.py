@@ -86,11 +86,35 @@ def sam_header(groups, sep="\t", version=None, argv=None, aligner_version=None):
     return "%s\n" % os.linesep.join(lines + list(groups))
 
 
+# minimap2's complement table (sketch.c `seq_comp_table`, what `mappy.revcomp` applies): the IUPAC codes in both cases, every
+# other byte unchanged.  On the XNA alphabets that means X stays X and Y -- an IUPAC code -- becomes R; the reference calls
+# mappy.revcomp on the called sequence as it is (io.py:133), so this is what its aligned records carry.  mappy is in no
+# image: the table is restated, and the generator of tests/golden/sam.json uses the same restatement as its stand-in.
+_COMP = {a: b for a, b in zip("ACGTUMRWSYKVHDBN", "TGCAAKYWSRMBDHVN")}
+_COMP.update({a.lower(): b.lower() for a, b in list(_COMP.items())})
+_COMP_TABLE = str.maketrans(_COMP)
+
+
+def revcomp(sequence):
+    """mappy.revcomp: reverse, then complement through minimap2's table."""
+    return sequence[::-1].translate(_COMP_TABLE)
+
+
 def sam_record(read_id, sequence, qstring, mapping=None, tags=None, sep="\t"):
-    """One SAM record as text (io.py:115-145).  Only the unaligned form exists here: flag 4, no reference, NM:i:0."""
+    """One SAM record as text (io.py:115-145).  Unaligned (mapping false): flag 4, no reference, NM:i:0.  Aligned: `mapping` is
+    a mappy.Alignment-shaped object (ctg, r_st, q_st, q_en, strand, mapq, cigar_str, NM, MD): flag 0 / 16, 1-based position,
+    the CIGAR wrapped in the soft clips of the unaligned query ends (swapped on the reverse strand), the sequence reverse
+    complemented on the reverse strand -- and the quality string left as it is, as the reference does.  The formatting is pinned
+    by tests/golden/sam.json; producing a mapping needs mappy (`--reference`), which is in no image."""
     if mapping:
-        raise NotImplementedError("aligned SAM records need a mappy alignment (minimap2 is in no image)")
-    record = [read_id, 4, "*", 0, 0, "*", "*", 0, 0, sequence, qstring, "NM:i:0"]
+        tail = len(sequence) - mapping.q_en
+        softclip = ["%sS" % mapping.q_st if mapping.q_st else "", mapping.cigar_str, "%sS" % tail if tail else ""]
+        forward = mapping.strand == +1
+        record = [read_id, 0 if forward else 16, mapping.ctg, mapping.r_st + 1, mapping.mapq,
+                  "".join(softclip if forward else softclip[::-1]), "*", 0, 0,
+                  sequence if forward else revcomp(sequence), qstring, "NM:i:%s" % mapping.NM, "MD:Z:%s" % mapping.MD]
+    else:
+        record = [read_id, 4, "*", 0, 0, "*", "*", 0, 0, sequence, qstring, "NM:i:0"]
     if tags is not None:
         record.extend(tags)
     return sep.join(map(str, record))
