@@ -1002,6 +1002,27 @@ __device__ __forceinline__ void dma16_sc1_off(const void *ubase, int byte_off, v
 #endif
 }
 
+// Round 5: the LEAN request.  The kernel is bound by its one wave's instruction COUNT (every instruction, scalar ones included,
+// takes an issue slot of >= 4 cycles), and a request used to cost seven: 64-bit base add (2), generic -> LDS pointer cast (2: a
+// null check), s_mov m0, s_nop, the load.  Here it costs three: the wave's LDS base (an SGPR) plus a literal straight into m0, the
+// lane's byte offset plus a literal (the VALU add doubles as the wait state m0 needs before an LDS-DMA), and the load from ONE
+// wave-uniform base (SGPR pair, per group-step) with the piece's column offset as the instruction's immediate.  The literals are
+// "n" operands: the callers' loop variables are constants after unrolling.
+__device__ __forceinline__ void dma16_lean_sc1(unsigned vlane, int vconst, const void *sbase, unsigned lds_wave, int lconst, int ioff)
+{
+    unsigned t;
+    asm volatile("s_add_i32 m0, %[lb], %[lc]\n\tv_add_u32 %[t], %[vc], %[vo]\n\tglobal_load_lds_dwordx4 %[t], %[sb] offset:%[io] sc1"
+                 : [t] "=&v"(t) : [lb] "s"(lds_wave), [lc] "n"(lconst), [vc] "n"(vconst), [vo] "v"(vlane), [sb] "s"(sbase), [io] "n"(ioff)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_lean_nt(unsigned vlane, int vconst, const void *sbase, unsigned lds_wave, int lconst)
+{
+    unsigned t;
+    asm volatile("s_add_i32 m0, %[lb], %[lc]\n\tv_add_u32 %[t], %[vc], %[vo]\n\tglobal_load_lds_dwordx4 %[t], %[sb] nt"
+                 : [t] "=&v"(t) : [lb] "s"(lds_wave), [lc] "n"(lconst), [vc] "n"(vconst), [vo] "v"(vlane), [sb] "s"(sbase)
+                 : "memory", "m0");
+}
+
 // 16-byte plain store: the line stays in the XCD's L2 (same asm form as the write-through one below)
 __device__ __forceinline__ void store16_l2(void *g, uint4 v)
 {
@@ -1086,6 +1107,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     float *sC0 = reinterpret_cast<float *>(sT + STP * 16 * ST_LD);                // [NG][32 units][64 chunks] cell state
     // input-projection tile of the step: [NG][64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
     unsigned char *sG0 = reinterpret_cast<unsigned char *>(sC0 + NG * LG_UNITS * LG_BN);
+    constexpr unsigned OFF_G = 2 * NPARTS * PIECE_BYTES + STP * 16 * ST_LD * 4 + NG * LG_UNITS * LG_BN * 4;   // of sG0 in the block
+    constexpr unsigned G_TILE = LG_BN * LG_UNITS * 16;                                                    // one group's gin tile
     int *sFlag = reinterpret_cast<int *>(sG0 + NG * LG_BN * LG_UNITS * 16);
     // DUAL: the first W_hh fragment lives in LDS (16 B per thread behind the flags and stamps) and is read back at the top of
     // every group-step: with all 512 registers taken hipcc otherwise parks half of it in scratch, and the reload -- a
@@ -1102,6 +1125,9 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    // LDS byte addresses as 32-bit integers (a generic pointer cast to the LDS address space costs a null check per use)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem_raw;
+    const unsigned lds_w = lds0 + (unsigned)wid * 1024u;       // this wave's 1 KiB slot of a request group (wave-uniform: an SGPR)
     const int members = F / LG_UNITS;
     const int ngroups = (p.nslab + LG_BN - 1) / LG_BN;
     const int gh = DUAL ? (ngroups + 1) / 2 : ngroups;          // workgroup slots: slot g serves group g (and g + gh)
@@ -1155,6 +1181,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     half_t *xg = nullptr;          // its exchange buffer [parity][part][64 rows][F]
     float *sC = sC0;
     unsigned char *sG = sG0;
+    unsigned lds_g = lds_w + OFF_G;   // LDS address of this wave's first 1 KiB of the group's gin tile
     constexpr size_t XPAR = (size_t)2 * LG_BN * F, XPART = (size_t)LG_BN * F;
     auto serve = [&](int gi) {
         const int g = grp + gi * gh;
@@ -1162,7 +1189,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         cnt = p.sync + (size_t)(p.grp0 + g) * LG_SYNC;
         xg = p.xh + (size_t)(p.grp0 + g) * (2 * 2 * LG_BN * F);
         sC = sC0 + gi * (LG_UNITS * LG_BN);
-        sG = sG0 + gi * (LG_BN * LG_UNITS * 16);
+        sG = sG0 + gi * G_TILE;
+        lds_g = lds_w + OFF_G + (unsigned)gi * G_TILE;
     };
 
     // ---- cell state lives in LDS as [unit][chunk] (the register file is full of W_hh): lane owns
@@ -1213,22 +1241,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // source cell (i & 31) ^ (row & 7): the lane part of the address is the same for all eight instructions.  Rows
     // past the slab's last chunk read whatever follows (other chunks' rows or the 64 slack rows behind the buffer):
     // their results are never stored.
-    auto issue_gin_d = [&](int tn, int d) {
+    auto issue_gin = [&](int tn) {
         // lane part recomputed per call (a few VALU) rather than kept in a register across the MFMA loop, where it would be
         // spilled and its reload (a scratch load + wait) would drain whatever is in flight
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const unsigned gin_lane = (unsigned)(((2 * wid + (lo >> 5)) * 128 + (((lo & 31) ^ ((2 * wid + (lo >> 5)) & 7)) * 4)) * 4);
-        // wave-uniform base (SGPRs) + 32-bit lane byte offset; member-major gin (xb_internal.h): this workgroup's 64 chunk
-        // rows of 128 gate columns are contiguous
-        const unsigned char *base = reinterpret_cast<const unsigned char *>(
-            p.gin + (((size_t)tn * members + mb) * N + cbase + 8 * d) * 128);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + gin_lane),
-                                         (__attribute__((address_space(3))) void *)(sG + (4 * d + wid) * 1024), 16, 0, 2 /* nt: read once */);
-    };
-    auto issue_gin = [&](int tn) {
+        // ONE wave-uniform base (an SGPR pair) per tile; request d adds 8 chunk rows = 4 KiB as a literal to the lane's byte
+        // offset and 4 KiB to the LDS address (lean request, see dma16_lean_sc1); member-major gin (xb_internal.h): this
+        // workgroup's 64 chunk rows of 128 gate columns are contiguous
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(p.gin + (((size_t)tn * members + mb) * N + cbase) * 128);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) issue_gin_d(tn, d);
+        for (int d = 0; d < 8; ++d) dma16_lean_nt(gin_lane, d * 4096, base, lds_g, d * 4096);
     };
     // (Requesting the tile still earlier -- in the free issue slots of the second-to-last piece, that piece ending on
     // vmcnt(8) -- was measured too: the poll no longer waits for it, but the first-piece landing and the MFMA phase grow by
@@ -1260,24 +1284,24 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
     constexpr int RPI = 64 / (POW2 ? CPR : 1);
     int lane_off_step = 0;      // computed once per (group-)step: as a value kept across the gate math it would be spilled
+    // POW2 (every shipped size): lane_off_step is the lane's BYTE offset inside the exchange image, the wave's row block
+    // included -- row RPI * wid + lane / CPR, swizzled cell -- and a request is the lean three-instruction form: request (part,
+    // j) of piece pc adds the literal part * (part stride) + 4 j RPI rows, the piece's column offset is the load's immediate
     auto issue_dma = [&](const half_t *xprev, int pc, int d) {
         const int lo = lane;
         const int lane_off = lane_off_step;
         const int part = NPARTS == 2 ? (d & 1) : 0;
-        const int q = wid + 4 * (NPARTS == 2 ? (d >> 1) : d);
-        unsigned char *dst = sPiece + (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + q * 1024;
-        if constexpr (I8) {
-            // byte image: row stride F bytes inside a part region of XPART * 2 bytes; lane_off_step is in bytes here
-            const unsigned char *base = reinterpret_cast<const unsigned char *>(xprev) + (size_t)part * (XPART * 2) +
-                                        (size_t)(RPI * q) * F + pc * KP;                       // uniform
-            dma16_sc1_off(base, lane_off, dst);
-        } else if (POW2) {
-            const half_t *base = xprev + part * XPART + (size_t)(RPI * q) * F + pc * KP;   // uniform
-            dma16_sc1_off(base, lane_off * 2, dst);
+        const int j = NPARTS == 2 ? (d >> 1) : d;
+        const int lconst = (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + 4 * j * 1024;
+        if constexpr (POW2) {
+            constexpr int ROWB = I8 ? F : F * 2;                         // bytes per row of one part of the image
+            const int vconst = part * (int)(XPART * 2) + 4 * j * RPI * ROWB;
+            dma16_lean_sc1((unsigned)lane_off, vconst, xprev, lds_w, lconst, pc * KP * ES);
         } else {
+            const int q = wid + 4 * j;
             const int cell = 64 * q + lo;
             const int row = cell / CPR, pos = cell % CPR;
-            dma16_sc1(xprev + part * XPART + (size_t)row * F + pc * KP + (pos ^ (row & SWZ)) * 8, dst);
+            dma16_sc1(xprev + part * XPART + (size_t)row * F + pc * KP + (pos ^ (row & SWZ)) * 8, sPiece + lconst + wid * 1024);
         }
     };
 
@@ -1323,8 +1347,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 {
                     int lo = lane;
                     if (PARK) asm volatile("" : "+v"(lo));
-                    const int lrow = lo / CPR;
-                    lane_off_step = POW2 ? lrow * F + (((lo % CPR) ^ ((RPI * wid + lrow) & SWZ)) * (I8 ? 16 : 8)) : 0;
+                    const int lrow = RPI * wid + lo / CPR;
+                    lane_off_step = POW2 ? lrow * (I8 ? F : F * 2) + (((lo % CPR) ^ (lrow & SWZ)) * 16) : 0;
                 }
                 if (!DUAL || !was_early) {
                     if (p.persistent && s > p.s_begin) {
@@ -1382,15 +1406,23 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 // piece buffer, the part and the column tile are immediates)
                 unsigned fa[KSP], qa[KSP / 2 > 0 ? KSP / 2 : 1][2];
                 {
+                    // one cell address each for the fp16 and the q8 fragments; every other k-step's is an XOR away: the
+                    // k-step moves bits 1.. of the cell index, the swizzle key XORs into the same bits, (a | b) ^ c splits
+                    // (round 5: 2 + 14 VALU per group-step instead of three per address)
                     int lo = lane;
                     asm volatile("" : "+v"(lo));
                     const unsigned r = (unsigned)lo & 31u, hs = (unsigned)lo >> 5;
+                    static_assert(!POW2 || I8 || 2 * KSP <= CPR, "the k-step bits stay inside the row (int8 limbs: only k-steps below KSP / 2 are used)");
+                    const unsigned fa0 = (r * CPR + (hs ^ (r & SWZ))) * 16;
+                    const unsigned qa0 = (r * CPR + ((2 * (1 - hs)) ^ (r & SWZ))) * 16;
 #pragma unroll
-                    for (int ks = 0; ks < KSP; ++ks) fa[ks] = (r * CPR + ((2 * ks + hs) ^ (r & SWZ))) * 16;
+                    for (int ks = 0; ks < KSP; ++ks)
+                        fa[ks] = POW2 ? fa0 ^ (unsigned)(ks << 5) : (r * CPR + ((2 * ks + hs) ^ (r & SWZ))) * 16;
 #pragma unroll
                     for (int b = 0; b < KSP / 2; ++b)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) qa[b][j] = (r * CPR + ((4 * b + 2 * (1 - hs) + j) ^ (r & SWZ))) * 16;
+                        for (int j = 0; j < 2; ++j)
+                            qa[b][j] = POW2 ? qa0 ^ (unsigned)((4 * b + j) << 4) : (r * CPR + ((4 * b + 2 * (1 - hs) + j) ^ (r & SWZ))) * 16;
                 }
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc) {
@@ -1479,6 +1511,21 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         const int kg = pc * KSP + ks;
                         if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
                         if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ONE counted wait per k-step (round 5): everything but the reads just issued has landed, i.e. every
+                        // fragment this k-step's MFMAs take (they were requested a k-step ago).  hipcc otherwise puts a counted
+                        // lgkmcnt in front of EVERY MFMA -- 130 s_waitcnt per group-step on a wave whose every instruction costs an
+                        // issue slot; with this wait in its scoreboard it emits none.  (the builtin needs a literal: spelled out)
+                        {
+                            constexpr int RD = NSPLIT == 3 ? 4 : 2;                    // ds_reads of one load_frags
+                            const bool more = ks + 1 < KSP, q8 = NSPLIT == 2 && (ks & 1) == 0;
+#define XB_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
+                            if (more && q8) XB_LGKM(RD + 4);
+                            else if (more) XB_LGKM(RD);
+                            else if (q8) XB_LGKM(4);
+                            else XB_LGKM(0);
+#undef XB_LGKM
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         // The next piece's requests, two per k-step so that the last one is issued by mid-piece and has landed at
                         // the barrier.  (XB_LSTM_DMA_SPREAD: every request directly behind ONE MFMA -- behind the FP8 ones, which
@@ -1570,6 +1617,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (tid == 0) { sStamp[8] += early ? 1 : 0; sStamp[9] += 1; }
 #endif
 
+            // the lane's eight cell states, requested together (round 5): hipcc otherwise reads each right before its use and
+            // waits for it there -- eight exposed LDS round trips per group-step.  The fragment registers are dead by now.
+            float cprev[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) cprev[nt][rg] = sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)];
+            __builtin_amdgcn_sched_barrier(0);
             // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
             // with the other half-wave's units so that each lane packs two ADJACENT units into one dword, written to
             // the [pair][chunk] staging (consecutive lanes -> consecutive dwords: conflict-free).
@@ -1585,7 +1640,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     const float gg = fast_tanh(acc[nt][4 * rg + 2]);
                     const float og = fast_sigmoid(acc[nt][4 * rg + 3]);
                     float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
-                    const float cn = __builtin_fmaf(ig, gg, fg * *cp);     // spelled out: lstm_quad_kernel must round the same way
+                    const float cn = __builtin_fmaf(ig, gg, fg * cprev[nt][rg]);     // spelled out: lstm_quad_kernel must round the same way
                     *cp = cn;
                     const float hv = og * fast_tanh(cn);
                     half_t hi, lo;
