@@ -1006,8 +1006,8 @@ __device__ __forceinline__ void dma16_sc1_off(const void *ubase, int byte_off, v
 // takes an issue slot of >= 4 cycles), and a request used to cost seven: 64-bit base add (2), generic -> LDS pointer cast (2: a
 // null check), s_mov m0, s_nop, the load.  Here it costs three: the wave's LDS base (an SGPR) plus a literal straight into m0, the
 // lane's byte offset plus a literal (the VALU add doubles as the wait state m0 needs before an LDS-DMA), and the load from ONE
-// wave-uniform base (SGPR pair, per group-step) with the piece's column offset as the instruction's immediate.  The literals are
-// "n" operands: the callers' loop variables are constants after unrolling.
+// wave-uniform base (SGPR pair, per group-step); the immediate offset stays 0 (it would move the LDS address as well).  The
+// literals are "n" operands: the callers' loop variables are constants after unrolling.
 __device__ __forceinline__ void dma16_lean_sc1(unsigned vlane, int vconst, const void *sbase, unsigned lds_wave, int lconst, int ioff)
 {
     unsigned t;
@@ -1063,6 +1063,10 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
 #ifndef XB_LSTM_DEFER_ARRIVE     // 1 (default): two groups per workgroup -- the arrival of a group-step is issued behind the first
                                  // piece-closing drain + barrier of the OTHER group's step instead of behind a drain of its own (A/B builds: 0)
 #define XB_LSTM_DEFER_ARRIVE 1
+#endif
+#ifndef XB_LSTM_PIPE_PIECES      // 1: the k-step pipeline runs across the piece boundary (see PIPE in lstm_kernel); with two piece buffers it measured
+                                 // 4 % SLOWER (profiles/r05_lstm_lean_ab.txt: the piece is then closed a k-step earlier and waits longer for its successors DMA)
+#define XB_LSTM_PIPE_PIECES 0
 #endif
 #ifdef XB_NO_SIGNAL
 #define XB_SIG(x) false
@@ -1295,8 +1299,10 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         const int lconst = (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + 4 * j * 1024;
         if constexpr (POW2) {
             constexpr int ROWB = I8 ? F : F * 2;                         // bytes per row of one part of the image
-            const int vconst = part * (int)(XPART * 2) + 4 * j * RPI * ROWB;
-            dma16_lean_sc1((unsigned)lane_off, vconst, xprev, lds_w, lconst, pc * KP * ES);
+            // (the piece's column offset goes into the literal as well: the load's IMMEDIATE offset is added to the LDS address
+            //  too -- measured in round 5: with offset:pc * 256 every piece but the first landed 256 pc bytes off)
+            const int vconst = part * (int)(XPART * 2) + 4 * j * RPI * ROWB + pc * KP * ES;
+            dma16_lean_sc1((unsigned)lane_off, vconst, xprev, lds_w, lconst, 0);
         } else {
             const int q = wid + 4 * j;
             const int cell = 64 * q + lo;
@@ -1424,13 +1430,27 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         for (int j = 0; j < 2; ++j)
                             qa[b][j] = POW2 ? qa0 ^ (unsigned)((4 * b + j) << 4) : (r * CPR + ((4 * b + 2 * (1 - hs) + j) ^ (r & SWZ))) * 16;
                 }
+                // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
+                // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use).  Round 5: the k-step
+                // pipeline runs ACROSS the piece boundary (PIPE): a piece that has a successor is closed (DMA drain +
+                // barrier) in front of its LAST k-step's MFMAs, whose fragments are in registers by then, and the
+                // successor's first fragments are requested behind that barrier -- their LDS latency, which used to sit
+                // exposed at the top of every piece with the matrix pipe drained, runs under those MFMAs.
+                half8 fh[2][2], fl[2][2];
+                v8i fq[2];
+                constexpr bool PIPE = !I8 && XB_LSTM_PIPE_PIECES != 0 && KSP % 2 == 0;
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc) {
                     const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
-                    // B fragments double-buffered by k-step: the 4 reads of k-step ks+1 are issued before the 6 MFMAs
-                    // of ks (sched_barrier keeps hipcc from sinking the reads back to their first use)
-                    half8 fh[2][2], fl[2][2];
-                    v8i fq[2];
+                    const unsigned char *bufn = sPiece + ((pc + 1) & 1) * NPARTS * PIECE_BYTES;      // the successor's buffer
+                    auto load_frags_at = [&](const unsigned char *bf, int ks, half8 (&h)[2], half8 (&l)[2]) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const unsigned char *a = bf + nt * (32 * CPR * 16) + fa[ks];
+                            h[nt] = *reinterpret_cast<const half8 *>(a);
+                            if (NSPLIT == 3) l[nt] = *reinterpret_cast<const half8 *>(a + PIECE_BYTES);
+                        }
+                    };
                     auto load_frags = [&](int ks, half8 (&h)[2], half8 (&l)[2]) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
@@ -1461,7 +1481,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             d0[nt] = *reinterpret_cast<const v4i *>(a + PIECE_BYTES);
                         }
                     };
-                    if constexpr (I8) load_dig(0, bd1[0], bd0[0]); else load_frags(0, fh[0], fl[0]);
+                    if constexpr (I8) load_dig(0, bd1[0], bd0[0]);
+                    else if (!PIPE || pc == 0) load_frags(0, fh[0], fl[0]);      // (PIPE, pc > 0: requested behind the previous piece's closing barrier)
                     // DUAL: has the group of the coming group-step arrived?  One look at its counter (its members had a whole
                     // group-step for it) at the start of the piece whose closing barrier publishes the answer: the last
                     // piece, or (EIL) the one before it.
@@ -1509,6 +1530,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 #pragma unroll
                     for (int ks = 0; ks < KSP; ++ks) {
                         const int kg = pc * KSP + ks;
+                        const bool closing = PIPE && ks + 1 == KSP && pc + 1 < NP;     // this piece is closed in front of these MFMAs
                         if (ks + 1 < KSP) load_frags(ks + 1, fh[(ks + 1) & 1], fl[(ks + 1) & 1]);
                         if (NSPLIT == 2 && (ks & 1) == 0) load_q8(ks >> 1);        // used by the odd k-step that follows
                         __builtin_amdgcn_sched_barrier(0);
@@ -1524,9 +1546,28 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             else if (more) XB_LGKM(RD);
                             else if (q8) XB_LGKM(4);
                             else XB_LGKM(0);
-#undef XB_LGKM
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if (closing) {
+                            // every fragment of this piece is in registers (lgkmcnt(0) above: nothing was requested in this
+                            // k-step).  Close the piece as its end used to: look-ahead flag, DMA drain, barrier, deferred arrival.
+                            XB_STAMP(3);
+                            if (DUAL && pc == PCHK && tid == 0) {
+                                sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
+                                XB_LGKM(0);
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
+                            __builtin_amdgcn_s_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (DEFER && pc == 0 && arrive_due) {      // the other group's exchange stores are at L2 in every wave
+                                if (tid == 0) __hip_atomic_fetch_add(arrive_due, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                arrive_due = nullptr;
+                            }
+                            XB_STAMP(7);
+                            load_frags_at(bufn, 0, fh[0], fl[0]);      // fh[0] is free: this k-step is odd (KSP is even)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#undef XB_LGKM
                         // The next piece's requests, two per k-step so that the last one is issued by mid-piece and has landed at
                         // the barrier.  (XB_LSTM_DMA_SPREAD: every request directly behind ONE MFMA -- behind the FP8 ones, which
                         // keep the pipe busy for 64 cycles, where the k-step has them -- instead of in pairs behind the k-step's
@@ -1564,6 +1605,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     }
+                    if (!PIPE || pc + 1 == NP) {
                     XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
                     if (DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
@@ -1573,6 +1615,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         arrive_due = nullptr;
                     }
                     XB_STAMP(7);   // piece DMA wait + barrier
+                    }
                 }
                 if constexpr (I8) {
                     // pre-activation = gin + row scale * (2^16 S11 + 2^8 (S10 + S01) + S00): every sum is exact, the fp32
