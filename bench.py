@@ -234,10 +234,12 @@ def main():
     # 512 chunks co-scheduled by the library (XB_FUSE) -- visible here as half as many launches as calls
     chunks_per_launch_factor = 5.0 * K / max(rec_launches, 1)       # calls served per recurrence launch of a layer (time slabs: < 1)
     fused = chunks_per_launch_factor > 1.5
-    dual = (N > 512 or fused) and os.environ.get("XB_LSTM_DUAL", "1") != "0"
+    # (round 5: 513..640 chunks run with ONE group per workgroup over up to ten group slots dealt over all XCDs, xb_api.hip WIDE)
+    wide_single = 512 < N <= 640 and not fused and os.environ.get("XB_LSTM_WIDE", "1") != "0"
+    dual = (N > 512 or fused) and not wide_single and os.environ.get("XB_LSTM_DUAL", "1") != "0"
     rec_traffic, rec_traffic_src = measured_traffic("lstm_kernel", nb, N, L, args.precision, rec_launches / float(K), fused)
     # template arguments as rocprofv3 prints them: KS, NSPLIT, DUAL, YALT (mixed: the q8 recurrence writes the fp16 residual the
-    # three-product GEMMs read, xb_encoder.hip lstm_kernel)
+    # three-product GEMMs read, xb_lstm.hip lstm_kernel)
     yalt = "true" if prec == _lib.XB_PREC_MIXED else "false"
     rec_kernel = "lstm_kernel<%d, %d, %s, %s>" % (F // 16, {0: 3, 1: 1, 2: 2, 3: 2, 4: 2}[prec], "true" if dual else "false", yalt)
     roofline = {"kernel": rec_kernel,

@@ -373,3 +373,42 @@ def test_reload_weights_on_live_context():
         ctx.load_state_dict(sd)
         assert np.abs(ctx.encode(x) - oracle.encode(x, sd, F, nb, 3)).max() < 1e-4
     ctx.close()
+
+
+@pytest.mark.parametrize("N,pair", [(513, False), (576, True), (640, False), (1025, False), (1280, False)])
+def test_wide_group_slots_equal_the_xcd_local_placement(N, pair, monkeypatch):
+    """Round 5, the batch cliffs: 513..640 chunks run as ONE launch with one group per workgroup over up to ten group slots
+    whose members are dealt over all XCDs (1025..1280: two groups per workgroup), instead of costing a second round; batches
+    of up to 640 chunks pair (two calls share a pass).  Placement and slot count change nothing: scores and called sequences
+    equal XB_LSTM_WIDE=0 byte for byte."""
+    import torch
+    F_, nb, L = 768, 5, 600
+    keys, shapes = encoder_shapes(F_, nb)
+    sd = seeded_state_dict(keys, shapes, seed=11)
+    gen = torch.Generator(device="cuda").manual_seed(N)
+    x = torch.randn((N, L), dtype=torch.float32, device="cuda", generator=gen)
+
+    def run(wide):
+        monkeypatch.setenv("XB_LSTM_WIDE", "1" if wide else "0")
+        ctx = _lib.Context(0, nb, 3, F_, 19, 5, 5.0, 2.0, L, N, precision=_lib.XB_PREC_MIXED)
+        monkeypatch.delenv("XB_LSTM_WIDE")
+        ctx.load_state_dict(sd)
+        paired = bool(pair and ctx.reserve_pairing())
+        bufs = [(torch.empty((N, ctx.T), dtype=torch.int8, device="cuda"), torch.empty((N,), dtype=torch.int32, device="cuda"))
+                for _ in range(2)]
+        for s, l in bufs:
+            ctx.basecall_chunks_dev(x.data_ptr(), N, "NACGTX", s.data_ptr(), l.data_ptr())
+        ctx.synchronize()
+        out = [(s.cpu().numpy(), l.cpu().numpy()) for s, l in bufs]
+        scores = ctx.encode(x.cpu().numpy())
+        ctx.close()
+        return out, scores, paired
+
+    wide, sw, paired_w = run(True)
+    local, sl, paired_l = run(False)
+    if pair:
+        assert paired_w and not paired_l          # 576 > 512: only the wide placement can co-schedule two such calls
+    assert np.array_equal(sw.view(np.uint32), sl.view(np.uint32))
+    for (a, la), (b, lb) in zip(wide, local):
+        assert np.array_equal(a, b) and np.array_equal(la, lb)
+    assert np.array_equal(wide[0][0], wide[1][0])

@@ -127,6 +127,8 @@ struct xb_ctx {
                                  // time at every batch size -- the step is bound by the kernels' summed CU-time -- and the decode at 0.49-0.52
                                  // of the HBM roofline instead of 0.35-0.42: profiles/r04_decode_placement.txt)
     int lstm_local = 1;          // XB_LSTM_LOCAL=0: always exchange h with write-through stores (A/B)
+    int lstm_wide = 1;           // XB_LSTM_WIDE: 1 (default) batches just above a launch's XCD-local capacity get up to cu_count / members group
+                                 // slots with the groups dealt over all XCDs instead of a second round (run_lstm_layer); 0: never
     int lstm_dual = 1;           // XB_LSTM_DUAL: 0 never, 1 when a launch would otherwise need a second chunk slab, 2 always
     int lstm_quad = 0;           // XB_LSTM_QUAD=1: the two-groups-per-workgroup launches run the software-pipelined kernel of xb_lstm_quad.h
                                  // where it applies (F = 768, q8 exchange image).  Bit-identical and SLOWER (41.9 vs 31.0 ms per layer of
@@ -553,7 +555,18 @@ int run_lstm_layer(xb_ctx *ctx, int layer, int n, const float *gin, half_t *xout
     if (mode == 2) {
         // a workgroup can serve two groups alternately (lstm_kernel DUAL): a launch then holds 2 * gmax groups, and a
         // group's hand-off latency is covered by the other group's step.  Used when the batch does not fit gmax groups.
-        const int gslab = gmax > 64 ? 64 : gmax;
+        // WIDE (round 5, the batch cliffs): the XCD-local placement holds gmax = 8 group slots (one group's 24 member workgroups per
+        // XCD), so 513 chunks -- nine groups -- used to take the two-groups-per-workgroup kernel over five slots, i.e. the time of
+        // 1024 chunks, and 1025 chunks a second launch.  The device has cu_count / members = 10 slots' worth of CUs: with a
+        // group's members dealt over ALL XCDs (LstmParams.spread: 3 per XCD and group, 30 of an XCD's 32 CUs at ten slots; the
+        // exchange then goes through write-through stores, a few percent slower per step) a launch holds up to 640 chunks with
+        // one group per workgroup and 1280 with two.  Used exactly where it saves a round: 513..640 and 1025..1280 chunks.
+        const int gslab0 = gmax > 64 ? 64 : gmax;
+        const int gwide = ctx->lstm_wide && ctx->cu_count / members > gslab0 ? (ctx->cu_count / members > 64 ? 64 : ctx->cu_count / members) : gslab0;
+        const bool wide = gwide > gslab0 && ((n > gslab0 * bn && n <= gwide * bn) ||
+                                             (dual_ok && ctx->lstm_dual == 1 && n > 2 * gslab0 * bn && n <= 2 * gwide * bn));
+        const int gslab = wide ? gwide : gslab0;
+        if (wide) p.spread = 1;
         const bool dual_batch = dual_ok && (ctx->lstm_dual == 2 ? n > bn : n > gslab * bn);
         const int slab = (dual_batch ? (2 * gslab > 64 ? 64 : 2 * gslab) : gslab) * bn;
         // the exchange buffer and the counters have 64 group slots: with the whole batch inside them every group keeps its
@@ -819,6 +832,7 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     }
     if (const char *e = getenv("XB_LSTM_MODE")) ctx->lstm_mode = atoi(e);
     if (const char *e = getenv("XB_LSTM_DUAL")) ctx->lstm_dual = atoi(e);
+    if (const char *e = getenv("XB_LSTM_WIDE")) ctx->lstm_wide = atoi(e) != 0;
     if (const char *e = getenv("XB_LSTM_QUAD")) ctx->lstm_quad = atoi(e) != 0;
     if (const char *e = getenv("XB_LSTM_LOCAL")) ctx->lstm_local = atoi(e) != 0;
     if (const char *e = getenv("XB_DECODE_ASYNC")) ctx->decode_async = atoi(e) != 0;
@@ -869,7 +883,15 @@ XB_API int xb_ctx_create(xb_ctx **out, int device, const xb_config *cfg)
     }
 
     // co-scheduling two calls: only where the pair fits one launch of two groups per workgroup
-    if (!(ctx->fuse_ok && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= 512)) ctx->fuse_ok = 0;
+    // (512 = the XCD-local capacity of a launch at features 768; with the wide placement -- run_lstm_layer -- a pair of up to
+    //  2 x 640 chunks still is ONE launch of two groups per workgroup, so batch sizes 513..640 pair as well)
+    int pair_cap = 512;
+    {
+        const int members = xb::lstm_members(cfg->features), slots = members > 0 ? ctx->cu_count / members : 0;
+        if (ctx->lstm_wide && members > 0 && 8 * ((ctx->cu_count / 8) / members) * xb::lstm_group_chunks() == 512 && slots > 8)
+            pair_cap = (slots > 64 ? 64 : slots) * xb::lstm_group_chunks();
+    }
+    if (!(ctx->fuse_ok && ctx->overlap == 1 && ctx->lstm_dual != 0 && cfg->max_batch <= pair_cap)) ctx->fuse_ok = 0;
     const size_t F = cfg->features;
     int rc = alloc_workspaces(ctx, cfg->max_batch);
     rc = rc ? rc : dev_alloc(ctx, &ctx->xh, (size_t)64 * 2 * 2 * 64 * F);

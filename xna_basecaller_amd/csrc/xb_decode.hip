@@ -328,7 +328,10 @@ __global__ __launch_bounds__(BS) XB_DEC_WAVES_ATTR void crf_decode_kernel(xb::De
     const int stc = act ? st : S - 1;              // clamped state (always a valid column)
     const int kcnt = LPS == 1 ? E : (ph == 0 ? H : E - H);   // valid local edge indices: r < kcnt
 
-    constexpr int NRS = VW == 4 ? (E + 3) / 4 : E;     // staging pieces per thread (BS * NRS * VW >= S * E >= cin)
+    // staging pieces per thread: BS * NRS * VW >= S * E >= cin.  BS >= LPS * S, so NRS * VW * LPS >= E is enough (round 5: with two
+    // lanes per state half the pieces -- nb = 5: one 16-byte piece per thread instead of two, the staged rows 4 KiB instead of
+    // 8 KiB, 25 KB of LDS per workgroup instead of 41 KB: FOUR workgroups per CU, as the registers allow, instead of three)
+    constexpr int NRS = VW == 4 ? (E + 4 * LPS - 1) / (4 * LPS) : (E + LPS - 1) / LPS;
     constexpr int cpad = BS * NRS * VW;                // staged row (floats)
     const int lim_m = VW == 4 ? (cin + 3) & ~3 : cin;  // vector loads may touch the row's padding columns
     const int Tpad = (T + RDEPTH13 - 1) / RDEPTH13 * RDEPTH13;   // multiple of both ring depths
@@ -755,7 +758,7 @@ hipError_t launch_nb_bs(const xb::DecodeParams &p, int vw, hipStream_t stream)
     // must mirror the kernel's LDS carve
     constexpr int E = NB + 1;
     auto lds_bytes = [&](int w) {
-        const int nrs = w == 4 ? (E + 3) / 4 : E;
+        const int nrs = w == 4 ? (E + 4 * LPS - 1) / (4 * LPS) : (E + LPS - 1) / LPS;      // the kernel's NRS
         const size_t cpad = (size_t)BS * nrs * w;
         const size_t b = sizeof(float) * (4 * cpad + 5 * (size_t)p.S + (size_t)LRING * (BS / 64)) +
                          sizeof(int) * (size_t)LRING * (BS / 64) + sizeof(float) * 4 + (size_t)p.T;
