@@ -230,8 +230,8 @@ def main():
     flop_launch = 5 * 2.0 * (4 * F) * F * T * N / max(rec_launches / K, 1)   # a layer may run as several time-slab launches
     rec_avg_s = 1e-3 * rec_ms / max(rec_launches, 1)
     rec_tflops = flop_launch / rec_avg_s / 1e12 if rec_avg_s > 0 else 0.0
-    # two chunk groups per workgroup: batches above 512 chunks, or two consecutive asynchronous calls of at most
-    # 512 chunks co-scheduled by the library (XB_FUSE) -- visible here as half as many launches as calls
+    # two chunk groups per workgroup: batches above 640 chunks, or two consecutive asynchronous calls of at most
+    # 640 chunks co-scheduled by the library (XB_FUSE) -- visible here as half as many launches as calls
     chunks_per_launch_factor = 5.0 * K / max(rec_launches, 1)       # calls served per recurrence launch of a layer (time slabs: < 1)
     fused = chunks_per_launch_factor > 1.5
     # (round 5: 513..640 chunks run with ONE group per workgroup over up to ten group slots dealt over all XCDs, xb_api.hip WIDE)

@@ -30,7 +30,9 @@
  *     input GEMM beside the current recurrence): give each in-flight batch its own d_seq / d_seq_len -- and its own d_signal
  *     that stays untouched until xb_synchronize (or until work ordered behind xb_result_stream has run).
  *   - a caller that keeps two batches in flight can have them CO-SCHEDULED: after xb_reserve_pairing (an explicit opt-in;
- *     contexts of at most 512 chunks; XB_FUSE=0 refuses) an xb_basecall_chunks_dev / xb_submit_chunks that finds nothing
+ *     contexts of at most 640 chunks at features 768 -- a pair must fit ONE recurrence launch of two chunk groups per
+ *     workgroup: 2 x 8 groups of 64 with a group's members on one XCD, 2 x 10 with the members dealt over all XCDs, which the
+ *     library does for 513..640 chunks, XB_LSTM_WIDE=0 restores the 512 limit; XB_FUSE=0 refuses) an xb_basecall_chunks_dev / xb_submit_chunks that finds nothing
  *     held back is itself held back (NOTHING is enqueued yet -- a device-wide synchronise or an event recorded on a stream
  *     fetched earlier does not cover it; its launch status is reported by the call that launches it) until the next such call
  *     arrives; the two batches then go through the encoder and the decode as one -- the recurrence serves two chunk groups

@@ -112,7 +112,7 @@ def test_pipelined_device_calls_match_blocking_calls(decode_async, monkeypatch):
 
 
 def test_two_calls_in_flight_share_one_pass(monkeypatch):
-    """Co-scheduling of two calls in flight (xb_reserve_pairing opts in; contexts of at most 512 chunks): the first of two
+    """Co-scheduling of two calls in flight (xb_reserve_pairing opts in; contexts of at most 640 chunks at features 768): the first of two
     asynchronous calls is held back and both go through the encoder and the decode as one batch -- half the recurrence launches,
     the same bytes as without; a held call is launched on its own by xb_result_stream / xb_synchronize / any other entry point,
     and a lone last call too.  Without the opt-in (and with XB_FUSE=0 even after it) every call is enqueued on its own."""

@@ -207,8 +207,9 @@ def argparser():
     parser.add_argument("--overlap", default=None, type=int)
     parser.add_argument("--chunksize", default=None, type=int)
     parser.add_argument("--batchsize", default=None, type=int,
-                        help="chunks per device call; multiples of 512 are the efficient sizes on MI355X (a recurrence launch "
-                             "serves 64-chunk groups, 8 or 16 at a time: 513 chunks cost 34 %% more per chunk than 512)")
+                        help="chunks per device call; 512 and 1024 are the efficient sizes on MI355X (a recurrence launch serves "
+                             "64-chunk groups, 8 or 16 at a time with a group on one XCD, up to 10 or 20 dealt over all XCDs: 513..640 "
+                             "and 1025..1280 chunks cost up to 11 %% more per chunk, 641 chunks 25 %% more)")
     parser.add_argument("--max-reads", default=0, type=int)
     parser.add_argument("--min-accuracy", default=0.95, type=float)
     parser.add_argument("--min-coverage", default=0.90, type=float)

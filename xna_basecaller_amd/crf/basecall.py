@@ -94,7 +94,7 @@ def compute_sequences_pipelined(model, batches, reverse=False):
     The device stage of `basecall`: (key, batch) stream -> (key, sequence (n,T) int8 left-packed ASCII) with several batches
     in flight on the device: batch k+1 is submitted (pinned staging, H2D on a copy stream, fused kernels, D2H) before
     batch k's result is waited for, so the GPU never idles while the host unpacks results.  Where the context co-schedules two
-    calls per device pass (Model.pipeline_depth: batches of at most 512 chunks) FOUR batches rotate through four staging
+    calls per device pass (Model.pipeline_depth: batches of at most 640 chunks) FOUR batches rotate through four staging
     slots -- batch k+3 is submitted before batch k is collected, so pair (k+2, k+3) is on the device, its H2D copies done,
     while the host waits for pair (k, k+1) -- otherwise two.  Results come out in input order, depth - 1 batches late.
     (compute_scores is the same operator, synchronous, with the reference's full result dict.)

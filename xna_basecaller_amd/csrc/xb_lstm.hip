@@ -129,6 +129,12 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
                                  // chain, and the gin / first-piece requests bunched into a third of the issue time fill the CU's request queue
 #define XB_LSTM_LEAN 2
 #endif
+#ifndef XB_LSTM_GIN_SPREAD       // 1: two groups per workgroup (no counted drain behind the exchange stores) -- the eight gin requests of the
+                                 // coming step go out ONE PER CELL inside the gate math instead of back to back behind the exchange stores, where each
+                                 // found the CU's request queue still full of its predecessors and held the wave ~50 cycles.  Measured: no gain
+                                 // (29.16-29.35 vs 29.06-29.13 ms per paired launch, profiles/r05_lstm_lean_ab.txt) -> 0 (default)
+#define XB_LSTM_GIN_SPREAD 0
+#endif
 #ifndef XB_LSTM_ONE_WAIT         // 1 (default, round 5): ONE counted LDS wait per k-step in front of its MFMAs; 0: hipcc's own wait in front of every MFMA (A/B builds)
 #define XB_LSTM_ONE_WAIT 1
 #endif
@@ -819,6 +825,18 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) cprev[nt][rg] = sC[(wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31)];
             if (XB_LSTM_CPREFETCH != 0) __builtin_amdgcn_sched_barrier(0);
+            // (XB_LSTM_GIN_SPREAD) the coming step's gin tile of this group: its buffer has been free since acc_from_gin at the top
+            // of this group-step; one request behind each cell's gate math
+            const bool gin_spread = XB_LSTM_GIN_SPREAD != 0 && LEAN && !GDIR && DEFER && second && p.persistent && s + 1 < p.s_end;
+            unsigned gs_lane = 0;
+            const unsigned char *gs_base = nullptr;
+            if (gin_spread) {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                gs_lane = (unsigned)(((2 * wid + (lo >> 5)) * 128 + (((lo & 31) ^ ((2 * wid + (lo >> 5)) & 7)) * 4)) * 4);
+                const int tn = p.reverse ? T - 2 - s : s + 1;
+                gs_base = reinterpret_cast<const unsigned char *>(p.gin + (((size_t)tn * members + mb) * N + cbase) * 128);
+            }
             // gates -> cell -> hidden.  A lane owns units 2*rg + hsel of chunk (lane & 31); v_permlane32_swap pairs them
             // with the other half-wave's units so that each lane packs two ADJACENT units into one dword, written to
             // the [pair][chunk] staging (consecutive lanes -> consecutive dwords: conflict-free).
@@ -836,6 +854,13 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     float *cp = sC + (wid * 8 + 2 * rg + hsel) * LG_BN + nt * 32 + (lane & 31);
                     const float cn = __builtin_fmaf(ig, gg, fg * cprev[nt][rg]);     // spelled out: lstm_quad_kernel must round the same way
                     *cp = cn;
+                    if constexpr (LEAN && !GDIR && DEFER) {
+                        if (gin_spread) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma16_lean_nt(gs_lane, (nt * 4 + rg) * 4096, gs_base, lds_g, (nt * 4 + rg) * 4096);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     const float hv = og * fast_tanh(cn);
                     half_t hi, lo;
                     split_f16(hv, hi, lo);
@@ -953,7 +978,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     load_gin_acc(acc, g1, s1);              // s1 <= s + 1 < s_end
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                issue_gin(p.reverse ? T - 2 - s : s + 1);
+                if (!gin_spread) issue_gin(p.reverse ? T - 2 - s : s + 1);
                 }
                 if (DEFER && second) {
                     // no drain here (see arrive_due); the barrier stays: the staging (and, YALT, piece buffer 1) is free for the
