@@ -3,6 +3,7 @@
 #                model, ragged batches, the serial schedule, every call on its own, the f16f8 opt-in, the driver's --steps 20)
 #   PART=prof  : rocprofv3 kernel-trace stats of the bench command + the PMC passes (FETCH_SIZE / WRITE_SIZE for roofline.traffic;
 #                MFMA-busy / clock / L2 / LDS for the GEMM, the recurrence and the decode), default and serial schedule
+#   PART=prof_serial: the PMC passes under the serial schedule (XB_OVERLAP=0)
 #   PART=stamps: the recurrence's cycle stamps (diagnostic library)
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
@@ -31,6 +32,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-chunks 0 > $O/stats512.log 2>&1
 cd $R
 bash tools/pmc_gemm.sh r05/pmc512 > $O/pmc512.log 2>&1
+fi
+if [ "$PART" = "prof_serial" ]; then
 XB_OVERLAP=0 bash tools/pmc_gemm.sh r05/pmc512_serial > $O/pmc512_serial.log 2>&1
 fi
 echo done > $O/done_$PART.txt
