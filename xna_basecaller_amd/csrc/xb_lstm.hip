@@ -129,6 +129,12 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
                                  // chain, and the gin / first-piece requests bunched into a third of the issue time fill the CU's request queue
 #define XB_LSTM_LEAN 2
 #endif
+#ifndef XB_LSTM_RING3            // 1: two groups per workgroup, piece count a multiple of three -- the pieces go through a ring of THREE buffers and are
+                                 // requested up to two pieces ahead (see R3 in lstm_kernel); 0 (default): two buffers, one piece ahead.  Measured:
+                                 // bit-identical and NEUTRAL (28.43-28.55 vs 28.51-28.56 ms per paired launch, profiles/r05_lstm_lean_ab.txt 8):
+                                 // what a piece's closing waits for is not its successor's landing
+#define XB_LSTM_RING3 0
+#endif
 #ifndef XB_LSTM_GIN_SPREAD       // 1: two groups per workgroup (no counted drain behind the exchange stores) -- the eight gin requests of the
                                  // coming step go out ONE PER CELL inside the gate math instead of back to back behind the exchange stores, where each
                                  // found the CU's request queue still full of its predecessors and held the wave ~50 cycles.  Measured: no gain
@@ -193,7 +199,6 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     unsigned char *sPiece = smem_raw;                                           // [2][NPARTS][PIECE_BYTES]
     // h staging for the 16-byte row stores: packed unit pairs, [NPARTS][16 pairs][ST_LD dwords] (chunk minor)
     unsigned *sT = reinterpret_cast<unsigned *>(smem_raw + 2 * NPARTS * PIECE_BYTES);
-    unsigned *sTy = reinterpret_cast<unsigned *>(smem_raw + NPARTS * PIECE_BYTES);   // YALT: [16][ST_LD] in piece buffer 1
     static_assert(!YALT || NPARTS * PIECE_BYTES >= 16 * ST_LD * 4, "piece buffer 1 holds the alternative y staging");
     float *sC0 = reinterpret_cast<float *>(sT + STP * 16 * ST_LD);                // [NG][32 units][64 chunks] cell state
     // input-projection tile of the step: [NG][64 chunks][32 cells of 16 B = the four gates of one unit], cell XOR (chunk & 31)
@@ -203,6 +208,21 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
     // GDIR: no tile -- what is left at sG0 is 1 KiB that the L2 prefetch requests write into (never read)
     constexpr unsigned G_TILE = GDIR ? 0 : LG_BN * LG_UNITS * 16;                                         // one group's gin tile
     int *sFlag = reinterpret_cast<int *>(sG0 + (GDIR ? 1024 : NG * LG_BN * LG_UNITS * 16));
+    // ---- R3 (round 5): a ring of THREE piece buffers without a byte of extra LDS.  With two groups per workgroup each group has a gin
+    // tile buffer of 32 KiB -- and a group's tile is dead from the moment its accumulators have been read at the top of the
+    // group-step until the next tile is requested at its end.  In between the buffer is the third piece buffer: piece pc sits in
+    // slot pc % 3 (piece buffers 0, 1, the current group's tile buffer) and is requested up to TWO pieces ahead:
+    //     during piece 0: nothing (the tile buffer is still being read by slower waves until this piece's closing barrier)
+    //     during piece 1: piece 2 (first half of the k-steps) and piece 3 (second half);   during piece pc >= 2: piece pc + 2,
+    //     i.e. during the last two pieces the first two pieces of the coming group-step (when the look-ahead poll, one piece
+    //     earlier than before, has seen the other group's members arrive).
+    // A piece then has two piece times to land instead of one (piece 2: one), and what closes a piece is a COUNTED wait that leaves
+    // the requests issued behind its successor's in flight -- the previous group-step's gin tile included, which the first
+    // closing used to wait for.  The alternative y staging (YALT) moves from piece buffer 1 (no longer idle during the gate math)
+    // into the group's tile buffer, and the tile request moves behind the barrier that ends the staging reads.
+    constexpr bool R3 = XB_LSTM_RING3 != 0 && DUAL && !I8 && !GDIR && (XB_LSTM_LEAN == 2 || XB_LSTM_LEAN == 1) &&
+                        (CPR & (CPR - 1)) == 0 && NP >= 3 && NP % 3 == 0 && G_TILE >= (unsigned)(NPARTS * PIECE_BYTES);
+    unsigned *sTy = reinterpret_cast<unsigned *>(smem_raw + NPARTS * PIECE_BYTES);   // YALT: [16][ST_LD] in piece buffer 1 (R3: re-pointed per group, see serve)
     // DUAL: the first W_hh fragment lives in LDS (16 B per thread behind the flags and stamps) and is read back at the top of
     // every group-step: with all 512 registers taken hipcc otherwise parks half of it in scratch, and the reload -- a
     // scratch load with vmcnt(0) behind it -- would wait for the other group's gin tile and y stores still in flight
@@ -285,6 +305,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         sC = sC0 + gi * (LG_UNITS * LG_BN);
         sG = sG0 + gi * G_TILE;
         lds_g = lds_w + OFF_G + (unsigned)gi * G_TILE;
+        if constexpr (R3) sTy = reinterpret_cast<unsigned *>(sG);
     };
 
     // ---- cell state lives in LDS as [unit][chunk] (the register file is full of W_hh): lane owns
@@ -440,7 +461,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         const int lane_off = lane_off_step;
         const int part = NPARTS == 2 ? (d & 1) : 0;
         const int j = NPARTS == 2 ? (d >> 1) : d;
-        const int lconst = (pc & 1) * NPARTS * PIECE_BYTES + part * PIECE_BYTES + 4 * j * 1024;
+        const bool slot2 = R3 && pc % 3 == 2;                     // the current group's tile buffer (LDS base lds_g, a runtime value)
+        const int lconst = (R3 ? (pc % 3 == 1 ? NPARTS * PIECE_BYTES : 0) : (pc & 1) * NPARTS * PIECE_BYTES) + part * PIECE_BYTES + 4 * j * 1024;
         if constexpr (POW2 && !LEAN) {
             // rounds 1-4: wave-uniform 64-bit base per request + the lane's byte offset (lane_off_step is the same value in both forms)
             constexpr int ROWB = I8 ? F : F * 2;
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             // (the piece's column offset goes into the literal as well: the load's IMMEDIATE offset is added to the LDS address
             //  too -- measured in round 5: with offset:pc * 256 every piece but the first landed 256 pc bytes off)
             const int vconst = part * (int)(XPART * 2) + 4 * j * RPI * ROWB + pc * KP * ES;
-            dma16_lean_sc1((unsigned)lane_off, vconst, xprev, lds_w, lconst, 0);
+            dma16_lean_sc1((unsigned)lane_off, vconst, xprev, slot2 ? lds_g : lds_w, lconst, 0);
         } else {
             const int q = wid + 4 * j;
             const int cell = 64 * q + lo;
@@ -475,7 +497,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
         issue_gin(p.reverse ? T - 1 - p.s_begin : p.s_begin);
     }
     }
-    bool early = false;     // DUAL: the first piece of the coming group-step was requested during the previous one
+    bool early = false;     // DUAL: the first piece (R3: the first two pieces) of the coming group-step was requested during the previous one
+    bool gin_prev = false;  // R3: the previous group-step requested a gin tile (eight requests the first closing leaves in flight)
     // DUAL with both groups present: the exchange stores of a group-step are not drained at its end; the next full drain +
     // barrier -- the one that closes the first piece of the other group's step, ~2.7 k cycles later -- covers them, and the
     // arrival goes out behind that (the group's hand-off still has most of the other group's step to complete: its members
@@ -503,6 +526,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             const half_t *xnext = p.xh + (size_t)(p.grp0 + grp + ngi * gh) * (2 * 2 * LG_BN * F) + (size_t)((ns - 1) & 1) * XPAR;
             const bool was_early = early;
             early = false;
+            const bool gin_was = gin_prev;
+            gin_prev = false;
             int go = 0;         // EIL: request the coming group-step's first piece during the last piece
 
             if (s > 0) {
@@ -545,8 +570,16 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     XB_STAMP(1);   // gin loads issued + wait for the group
 #pragma unroll
                     for (int d = 0; d < NDMA; ++d) issue_dma(xprev, 0, d);
+                    if constexpr (R3) {
+#pragma unroll
+                        for (int d = 0; d < NDMA; ++d) issue_dma(xprev, 1, d);
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NDMA) : "memory");   // all but the second piece's requests
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first piece and the gin tile (this wave's shares)
                     __syncthreads();
+                    }
                 }
                 // (early: the drain wait and barrier that ended the previous group-step covered the first piece and this
                 //  group's gin tile, both older than the exchange stores drained there)
@@ -598,8 +631,22 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 constexpr bool PIPE = !I8 && XB_LSTM_PIPE_PIECES != 0 && KSP % 2 == 0;
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc) {
-                    const unsigned char *buf = sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
-                    const unsigned char *bufn = sPiece + ((pc + 1) & 1) * NPARTS * PIECE_BYTES;      // the successor's buffer
+                    const unsigned char *buf = R3 ? (pc % 3 == 2 ? sG : sPiece + (pc % 3) * NPARTS * PIECE_BYTES) : sPiece + (pc & 1) * NPARTS * PIECE_BYTES;
+                    const unsigned char *bufn = R3 ? ((pc + 1) % 3 == 2 ? sG : sPiece + ((pc + 1) % 3) * NPARTS * PIECE_BYTES)
+                                                   : sPiece + ((pc + 1) & 1) * NPARTS * PIECE_BYTES;      // the successor's buffer
+                    // what closes this piece.  R3: everything has landed but the requests issued behind the successor's -- this piece's
+                    // (piece 1: its second half), and at the first closing the previous group-step's gin tile; else: everything
+                    auto close_wait = [&]() {
+#define XB_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+                        if constexpr (R3) {
+                            if (pc == 0) { if (was_early && gin_was) XB_VM(8); else XB_VM(0); }
+                            else if (pc == 1) { if (NP > 3 || go) XB_VM(NDMA); else XB_VM(0); }
+                            else { if (pc + 2 < NP || go) XB_VM(NDMA); else XB_VM(0); }
+                        } else {
+                            XB_VM(0);
+                        }
+#undef XB_VM
+                    };
                     auto load_frags_at = [&](const unsigned char *bf, int ks, half8 (&h)[2], half8 (&l)[2]) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
@@ -643,10 +690,14 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     // DUAL: has the group of the coming group-step arrived?  One look at its counter (its members had a whole
                     // group-step for it) at the start of the piece whose closing barrier publishes the answer: the last
                     // piece, or (EIL) the one before it.
-                    constexpr int PCHK = EIL ? NP - 2 : NP - 1;
-                    if (DUAL && pc == PCHK && nxt_h && nxt_poll && tid == 0)
-                        seen = __hip_atomic_load(ncnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (EIL && pc == NP - 1) go = __builtin_amdgcn_readfirstlane(nxt_h ? sFlag[1] : 0);
+                    constexpr int PCHK = R3 ? NP - 3 : (EIL ? NP - 2 : NP - 1);
+                    if (DUAL && pc == PCHK && nxt_h && nxt_poll && tid == 0) {
+                        // (R3: as inline asm -- hipcc would guard the use of a load it can see with vmcnt(0), and this wave would drain
+                        //  the requests the counted wait of the piece's closing is there to leave in flight)
+                        if constexpr (R3) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen) : "v"(ncnt) : "memory");
+                        else seen = __hip_atomic_load(ncnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (R3 ? pc == NP - 2 : (EIL && pc == NP - 1)) go = __builtin_amdgcn_readfirstlane(nxt_h ? sFlag[1] : 0);
                     if constexpr (I8) {
                         constexpr int KBP = KP / 32;            // 32-column blocks per piece = DMA requests per wave and piece
                         static_assert(NDMA == KBP, "one piece request per block");
@@ -709,11 +760,16 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             // every fragment of this piece is in registers (lgkmcnt(0) above: nothing was requested in this
                             // k-step).  Close the piece as its end used to: look-ahead flag, DMA drain, barrier, deferred arrival.
                             XB_STAMP(3);
-                            if (DUAL && pc == PCHK && tid == 0) {
+                            if (!R3 && DUAL && pc == PCHK && tid == 0) {
                                 sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
                                 XB_LGKM(0);
                             }
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
+                            close_wait();                                      // next piece landed (this wave's share)
+                            if (R3 && pc == PCHK) {                            // (the asm poll load is older than this piece's requests: landed)
+                                asm volatile("" : "+v"(seen));
+                                if (tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
                             __builtin_amdgcn_s_barrier();
                             __builtin_amdgcn_sched_barrier(0);
                             if (DEFER && pc == 0 && arrive_due) {      // the other group's exchange stores are at L2 in every wave
@@ -730,9 +786,19 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                         // keep the pipe busy for 64 cycles, where the k-step has them -- instead of in pairs behind the k-step's
                         // MFMAs: measured, not adopted.)
                         auto dma_slot = [&](int j) {
+                            if constexpr (R3) {
+                                // piece 0: nothing; piece 1: pieces 2 and 3 (one half of the k-steps each); piece pc >= 2: piece pc + 2;
+                                // targets beyond this group-step's last piece are the coming group-step's first two (if it is ready)
+                                const int i = 2 * ks + j;
+                                if (pc == 0 || i >= (pc == 1 ? 2 : 1) * NDMA) return;
+                                const int tgt = pc == 1 ? 2 + i / NDMA : pc + 2;
+                                if (tgt < NP) issue_dma(xprev, tgt, i % NDMA);
+                                else if (go) issue_dma(xnext, tgt - NP, i % NDMA);
+                            } else {
                             if (2 * ks + j >= NDMA) return;
                             if (pc + 1 < NP) issue_dma(xprev, pc + 1, 2 * ks + j);
                             else if (EIL && go) issue_dma(xnext, 0, 2 * ks + j);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         };
                         constexpr bool XB_DMA_SPREAD = XB_LSTM_DMA_SPREAD != 0;
@@ -764,9 +830,19 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     }
                     if (!PIPE || pc + 1 == NP) {
                     XB_STAMP(3);   // piece compute (ds_read + MFMA + next piece's DMA issue)
-                    if (DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next piece landed (this wave's share)
+                    if (!R3 && DUAL && pc == PCHK && tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
+                    close_wait();                                      // next piece landed (this wave's share)
+                    if constexpr (R3) {                                // (raw barrier: __syncthreads() may drain the requests left in flight)
+                        if (pc == PCHK) {                              // the asm poll load is older than this piece's requests: it has landed
+                            asm volatile("" : "+v"(seen));
+                            if (tid == 0) sFlag[1] = (nxt_h && (!nxt_poll || seen >= ntarget)) ? 1 : 0;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
                     __syncthreads();
+                    }
                     if (DEFER && pc == 0 && arrive_due) {      // the other group's exchange stores are at L2 in every wave
                         if (tid == 0) __hip_atomic_fetch_add(arrive_due, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         arrive_due = nullptr;
@@ -806,8 +882,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
 
             // DUAL: request the first piece of the coming group-step now -- it lands behind the gate math, and the drain
             // wait below (everything but the eight youngest operations) covers it
-            if (EIL) {
-                early = go != 0;    // requested inside the last piece; its closing wait and barrier have landed it
+            if (EIL || R3) {
+                early = go != 0;    // requested inside the last piece(s); the closing wait and barrier have landed it
             } else if (DUAL && nxt_h && sFlag[1] != 0) {
 #pragma unroll
                 for (int d = 0; d < NDMA; ++d) issue_dma(xnext, 0, d);
@@ -827,7 +903,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
             if (XB_LSTM_CPREFETCH != 0) __builtin_amdgcn_sched_barrier(0);
             // (XB_LSTM_GIN_SPREAD) the coming step's gin tile of this group: its buffer has been free since acc_from_gin at the top
             // of this group-step; one request behind each cell's gate math
-            const bool gin_spread = XB_LSTM_GIN_SPREAD != 0 && LEAN && !GDIR && DEFER && second && p.persistent && s + 1 < p.s_end;
+            const bool gin_spread = XB_LSTM_GIN_SPREAD != 0 && !R3 && LEAN && !GDIR && DEFER && second && p.persistent && s + 1 < p.s_end;
             unsigned gs_lane = 0;
             const unsigned char *gs_base = nullptr;
             if (gin_spread) {
@@ -962,6 +1038,25 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 }
                 }
             }
+            // layer output for the next layer: plain stores, nobody in this launch reads them
+            // (address recomputed from the thread index here: a value kept across the loop gets spilled, and its reload -- a
+            // scratch load with a vmcnt(0) behind it -- would wait for the gin DMAs just issued)
+            bool y_done = false;
+            auto store_y = [&]() {
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                const int n = cbase + (to >> 2);
+                if (n <= nlast) {
+                    const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
+                    if (XB_SIG(p.sig_flag)) {           // read by another stream's kernel while this launch is still running: write-through
+                        store16_sc1(p.y_hi + o, vhi);
+                        store16_sc1(p.y_lo + o, vylo);
+                    } else {
+                        *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
+                        *reinterpret_cast<uint4 *>(p.y_lo + o) = vylo;
+                    }
+                }
+            };
             XB_STAMP(4);   // pointwise + exchange stores issued
             if (p.persistent && s + 1 < p.s_end) {
                 // next step's gin tile (eight LDS-DMAs per wave), then every storing wave drains its exchange stores: all but
@@ -978,17 +1073,34 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                     load_gin_acc(acc, g1, s1);              // s1 <= s + 1 < s_end
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                if (!gin_spread) issue_gin(p.reverse ? T - 2 - s : s + 1);
+                if (!R3 && !gin_spread) issue_gin(p.reverse ? T - 2 - s : s + 1);
                 }
                 if (DEFER && second) {
                     // no drain here (see arrive_due); the barrier stays: the staging (and, YALT, piece buffer 1) is free for the
                     // other group's step once every wave has read it
+                    if constexpr (R3) { store_y(); y_done = true; }    // (before the tile requests: the first closing of the coming
+                                                                      //  group-step leaves exactly those eight in flight)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     arrive_due = cnt;
+                    if constexpr (R3) {     // the tile buffer held the alternative y staging: requests only behind the barrier
+                        issue_gin(p.reverse ? T - 2 - s : s + 1);
+                        gin_prev = true;
+                    }
                     XB_STAMP(5);
                     XB_STAMP(6);
+                } else if constexpr (R3) {
+                    // one group in this slot: its next step waits for this very arrival -- drain everything (nothing is younger than
+                    // the exchange stores), arrive, THEN the tile requests (behind the barrier, as above)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    XB_STAMP(5);
+                    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    XB_STAMP(6);
+                    issue_gin(p.reverse ? T - 2 - s : s + 1);
+                    gin_prev = true;
                 } else {
                 if constexpr (GDIR && XB_GIN_PREFETCH != 0) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");      // all but the prefetch and the eight loads
                 else if constexpr (GDIR) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -1007,24 +1119,7 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 }
                 __syncthreads();   // sT is rewritten next step (this also lands an early first piece)
             }
-            // layer output for the next layer: plain stores, nobody in this launch reads them
-            // (address recomputed from the thread index here: a value kept across the loop gets spilled, and its reload -- a
-            // scratch load with a vmcnt(0) behind it -- would wait for the gin DMAs just issued)
-            {
-                int to = tid;
-                asm volatile("" : "+v"(to));
-                const int n = cbase + (to >> 2);
-                if (n <= nlast) {
-                    const size_t o = ((size_t)t * N + n) * F + mb * LG_UNITS + (to & 3) * 8;
-                    if (XB_SIG(p.sig_flag)) {           // read by another stream's kernel while this launch is still running: write-through
-                        store16_sc1(p.y_hi + o, vhi);
-                        store16_sc1(p.y_lo + o, vylo);
-                    } else {
-                        *reinterpret_cast<uint4 *>(p.y_hi + o) = vhi;
-                        *reinterpret_cast<uint4 *>(p.y_lo + o) = vylo;
-                    }
-                }
-            }
+            if (!y_done) store_y();
         }
         // time slab complete: every wave's output stores are at the coherence point, then one arrival per workgroup; the last
         // one to arrive publishes the slab to the stream that waits on the flag
