@@ -731,6 +731,20 @@ def test_sam_text_output_matches_the_reference_functions(tmp_path):
         f = a["sam_record"].split("\t")
         assert f[1] == ("0" if m.strand == 1 else "16") and int(f[3]) == m.r_st + 1 and len(f[9]) == len(f[10])
     assert xio.revcomp("ACGTXYacgtN") == "NacgtRXACGT" and xio.revcomp("") == ""
+    # ... and the writer emits that record for a result that carries a mapping (what an aligner stage would hand it)
+    a0 = g["aligned"][2]
+    rd0 = types.SimpleNamespace(**g["records"][0]["read"])
+    rd0.signal = np.zeros(50, np.float32)
+    rd0.start = rd0.duration = rd0.template_start = rd0.template_duration = 0.0
+    rd0.read_id = a0["read_id"]
+    rd0.tagdata = lambda: []
+    buf = pyio.StringIO()
+    wa = xio.Writer("w", iter([(rd0, {"sequence": a0["sequence"], "qstring": a0["qstring"], "mean_qscore": 11.0,
+                                      "mapping": types.SimpleNamespace(**a0["mapping"])})]),
+                    fd=buf, group_key=model, groups=set(), summary=str(tmp_path / "a_summary.tsv"))
+    wa.run()
+    line = buf.getvalue()[len(xio.sam_header([])):].rstrip("\n")
+    assert line.split("\t")[:11] == a0["sam_record_no_tags"].split("\t")[:11] and "\tNM:i:1\tMD:Z:3^C5\t" in line + "\t"
     # the writer: header first, then the records in order, an empty call skipped, summary rows as for FASTQ
     out = pyio.StringIO()
     results = [(r, {"sequence": rec["sequence"], "qstring": rec["qstring"], "mean_qscore": float(rec["tags"][1].split(":")[2])})
