@@ -5,6 +5,7 @@
 #include "xb_enc_common.h"
 
 namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ======================================================================================
 // LSTM recurrence.
@@ -128,6 +129,11 @@ __device__ unsigned long long g_lstm_stamps[10];   // 0..7 cycle sums, 8 = early
                                  // per workgroup -5 % per launch; with ONE group the launch gets 4-6 % SLOWER -- its critical path is the hand-off
                                  // chain, and the gin / first-piece requests bunched into a third of the issue time fill the CU's request queue
 #define XB_LSTM_LEAN 2
+#endif
+#ifndef XB_LSTM_PKGATE           // 1: the gate math on PAIRS of cells with the packed fp32 VALU (v_pk_mul / v_pk_add / v_pk_fma_f32: two lanes' worth of
+                                 // work per issue slot) -- the same IEEE operations in the same order per cell, so the results do not change;
+                                 // 0: one cell at a time (rounds 1-4; A/B builds).  Not combined with XB_LSTM_GIN_SPREAD.
+#define XB_LSTM_PKGATE 1
 #endif
 #ifndef XB_LSTM_RING3            // 1: two groups per workgroup, piece count a multiple of three -- the pieces go through a ring of THREE buffers and are
                                  // requested up to two pieces ahead (see R3 in lstm_kernel); 0 (default): two buffers, one piece ahead.  Measured:
@@ -921,8 +927,40 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                 unsigned phi[4], plo[4];
                 float hq[4], lq[4];
                 unsigned dg1[4], dg0[4];            // NSPLIT == 4: digit bytes of the four units
+                constexpr bool PKG = XB_LSTM_PKGATE != 0 && XB_LSTM_GIN_SPREAD == 0;
+                float og4[4], th4[4];
+                if constexpr (PKG) {
+                    // sigmoid(x) = rcp(1 + exp2(-log2e x)), tanh(x) = 1 - 2 rcp(exp2(2 log2e x) + 1): fast_sigmoid / fast_tanh spelled out on pairs
+                    // (x * (2 log2e) is (x + x) * log2e bit for bit: a power-of-two factor commutes with the rounding)
+                    constexpr float L2E = 1.44269504088896340736f;
+                    const f32x2 K_IF = {-L2E, -L2E}, K_GO = {2.0f * L2E, -L2E}, K_T = {2.0f * L2E, 2.0f * L2E}, ONE = {1.0f, 1.0f}, M2 = {-2.0f, -2.0f};
+                    auto exp2_2 = [](f32x2 v) { return (f32x2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; };
+                    auto rcp_2 = [](f32x2 v) { return (f32x2){__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; };
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        const int r0 = 2 * rp, r1 = r0 + 1;
+                        const f32x2 if0 = rcp_2(exp2_2((f32x2){acc[nt][4 * r0 + 0], acc[nt][4 * r0 + 1]} * K_IF) + ONE);      // i, f of cell r0
+                        const f32x2 go0 = rcp_2(exp2_2((f32x2){acc[nt][4 * r0 + 2], acc[nt][4 * r0 + 3]} * K_GO) + ONE);      // rcp of g's tanh, o
+                        const f32x2 if1 = rcp_2(exp2_2((f32x2){acc[nt][4 * r1 + 0], acc[nt][4 * r1 + 1]} * K_IF) + ONE);
+                        const f32x2 go1 = rcp_2(exp2_2((f32x2){acc[nt][4 * r1 + 2], acc[nt][4 * r1 + 3]} * K_GO) + ONE);
+                        const f32x2 gg = __builtin_elementwise_fma((f32x2){go0.x, go1.x}, M2, ONE);
+                        const f32x2 ig = {if0.x, if1.x}, fg = {if0.y, if1.y}, og = {go0.y, go1.y};
+                        const f32x2 cn = __builtin_elementwise_fma(ig, gg, fg * (f32x2){cprev[nt][r0], cprev[nt][r1]});
+                        sC[(wid * 8 + 2 * r0 + hsel) * LG_BN + nt * 32 + (lane & 31)] = cn.x;
+                        sC[(wid * 8 + 2 * r1 + hsel) * LG_BN + nt * 32 + (lane & 31)] = cn.y;
+                        // (h = o * tanh(c) itself stays a scalar product below: hipcc contracts it into the f16 split -- fma_mix forms that
+                        //  take the residual from the UNROUNDED product -- and a packed multiply in front of that would change the low bits)
+                        const f32x2 th = __builtin_elementwise_fma(rcp_2(exp2_2(cn * K_T) + ONE), M2, ONE);
+                        og4[r0] = og.x; og4[r1] = og.y;
+                        th4[r0] = th.x; th4[r1] = th.y;
+                    }
+                }
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    float hv;
+                    if constexpr (PKG) {
+                        hv = og4[rg] * th4[rg];
+                    } else {
                     const float ig = fast_sigmoid(acc[nt][4 * rg + 0]);
                     const float fg = fast_sigmoid(acc[nt][4 * rg + 1]);
                     const float gg = fast_tanh(acc[nt][4 * rg + 2]);
@@ -937,7 +975,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(xb::LstmParams p)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    const float hv = og * fast_tanh(cn);
+                    hv = og * fast_tanh(cn);
+                    }
                     half_t hi, lo;
                     split_f16(hv, hi, lo);
                     phi[rg] = (unsigned)__builtin_bit_cast(unsigned short, hi);
