@@ -365,6 +365,21 @@ void fragment_major(const std::vector<half_t> &hi, const std::vector<half_t> &lo
     out.assign((size_t)nk * *kstride, 0);
     const unsigned char *hib = reinterpret_cast<const unsigned char *>(hi.data());
     const unsigned char *lob = reinterpret_cast<const unsigned char *>(lo.data());
+    if (nsplit == 3 && XB_GEMM_S16 != 0) {
+        // the 16x16x32 arithmetic: piece 2 * part + c = rows 16 c .. 16 c + 15 of the block, lane l = row (l & 15), k 8 (l >> 4) .. + 8
+        for (int kt = 0; kt < nk; ++kt)
+            for (int nt = 0; nt < nt32; ++nt)
+                for (int c = 0; c < 2; ++c)
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = nt * 32 + c * 16 + (l & 15);
+                        if (r >= rows) continue;
+                        unsigned char *blk = out.data() + (size_t)kt * *kstride + (size_t)nt * npc * 1024 + (size_t)l * 16;
+                        const size_t e0 = (size_t)r * ld + (size_t)kt * 32 + (size_t)(l >> 4) * 8;
+                        memcpy(blk + c * 1024, hib + e0 * 2, 16);
+                        memcpy(blk + (2 + c) * 1024, lob + e0 * 2, 16);
+                    }
+        return;
+    }
     for (int kt = 0; kt < nk; ++kt)
         for (int nt = 0; nt < nt32; ++nt)
             for (int l = 0; l < 64; ++l) {

@@ -160,12 +160,44 @@ __device__ __forceinline__ bool gemm_tile_origin(const xb::GemmParams &p, int &m
 }
 
 // epilogue shared by the GEMM kernels: a wave holds 4 x 2 accumulator tiles of 32x32 whose origin is (mw, nw): rows
-// mw .. mw + 127, columns nw .. nw + 63 (nw a multiple of 64); a lane holds column (lane & 31) and 16 rows of each tile.
+// mw .. mw + 127, columns nw .. nw + 63 (nw a multiple of 64); a lane holds column (lane & 31) and 16 rows of each tile:
+// register r of a lane in half h = lane >> 5 is row (r & 3) + 8 (r >> 2) + 4 h of the tile (the 32x32 MFMA's own layout) or,
+// L16 (the 16x16x32 arithmetic, see acc16_lines), row (r & 7) + 16 (r >> 3) + 8 h.
 // The bias is loaded ONCE, ahead of all stores: a load inside the store loop makes every store wait (vmcnt counts stores
 // too) for the one before it.
-template <int EPI>
+template <bool L16>
+__device__ __forceinline__ constexpr int acc_row(int r) { return L16 ? (r & 7) + 16 * (r >> 3) : (r & 3) + 8 * (r >> 2); }
+
+// The 16x16x32 kernels' accumulators -- 8 x 4 tiles of 16x16, a lane holding column (lane & 15) and rows 4 (lane >> 4) + r --
+// rearranged so that, as with the 32x32 tiles, every half-wave holds 32 CONSECUTIVE columns of one row (whole 128-byte lines per
+// store instruction: what the memory side wants, see gemm8r_kernel): v_permlane16_swap_b32 on register r of two tiles side by
+// side leaves [a.row0 b.row0 a.row2 b.row2] and [a.row1 b.row1 a.row3 b.row3] (rows = groups of 16 lanes;
+// profiles/r05_mfma_shape_ubench.txt), i.e. columns 32 jp + (lane & 31) of tile rows r + 8 (lane >> 5) and r + 4 + 8 (lane >> 5).
+// (inline asm: hipcc 7.2 miscompiles __builtin_amdgcn_permlane16_swap on elements of vector-typed values -- it swaps element 0
+//  only and reuses the result for the other three; the accumulators were written by MFMAs that retired long before -- the loop's
+//  closing s_waitcnt vmcnt(0) lies in between -- so no wait states are owed here)
+__device__ __forceinline__ void acc16_lines(const f32x4 (&a)[8][4], floatx16 (&o)[4][2])
+{
+    asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u = a[2 * i + ib][2 * jp][r], v = a[2 * i + ib][2 * jp + 1][r];
+                    asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+                    o[i][jp][ib * 8 + r] = u;
+                    o[i][jp][ib * 8 + 4 + r] = v;
+                }
+}
+
+template <int EPI, bool L16 = false>
 __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const floatx16 (&acc)[4][2], int mw, int nw, int lane)
 {
+    constexpr int HS = L16 ? 8 : 4;              // rows between the two lane halves
     if (mw >= p.M || nw >= p.Nn) return;         // a wave wholly outside the matrix (edge tiles)
     float bj[2];
 #pragma unroll
@@ -197,24 +229,24 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
         } else {
             tile = p.out_f32 + (size_t)mw * p.ldc + nw;
         }
-        const int loff = (4 * (lane >> 5)) * ld + (lane & 31);
+        const int loff = (HS * (lane >> 5)) * ld + (lane & 31);
         if (c0 + 128 <= n) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld;
+                    float *rowp = tile + (size_t)(i * 32 + acc_row<L16>(r)) * ld;
 #pragma unroll
                     // non-temporal: 12.6 GB per layer that nobody reads again before the L2 / Infinity Cache have turned over
                     for (int j = 0; j < 2; ++j) __builtin_nontemporal_store(acc[i][j][r] + bj[j], rowp + loff + j * 32);
                 }
         } else {
-            const int cl = c0 + 4 * (lane >> 5);          // chunk index of this lane's row 0 (before wrapping)
+            const int cl = c0 + HS * (lane >> 5);          // chunk index of this lane's row 0 (before wrapping)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const int rr = i * 32 + acc_row<L16>(r);
                     const int c = cl + rr;
                     const int k = (c >= n) + (c >= 2 * n) + (c >= 3 * n);
                     float *rowp = tile + (size_t)rr * ld + (long long)k * wrap;
@@ -228,12 +260,12 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
         // interior wave tile of the CRF linear layer without the blank column (the fused path's layout): rows ldc apart, no
         // bounds checks, no per-element column arithmetic
         float *tile = p.out_f32 + (size_t)mw * p.ldc + nw;
-        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+        const int loff = (HS * (lane >> 5)) * p.ldc + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float *rowp = tile + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+                float *rowp = tile + (size_t)(i * 32 + acc_row<L16>(r)) * p.ldc;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rowp[loff + j * 32] = p.scale * fast_tanh(acc[i][j][r] + bj[j]);
             }
@@ -242,14 +274,14 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
     if (EPI == xb::EPI_SILU_SPLIT && interior) {
         // interior tile of the conv3 GEMM: hi as fp16, second part as fp16 residual or q8 bytes; no bounds checks
         const size_t tile = (size_t)mw * p.ldc + nw;       // element offset of the wave's tile
-        const int loff = (4 * (lane >> 5)) * p.ldc + (lane & 31);
+        const int loff = (HS * (lane >> 5)) * p.ldc + (lane & 31);
         unsigned char *q8base = reinterpret_cast<unsigned char *>(p.out_lo) + tile * 2;    // nw is a multiple of 32
-        const int qoff = (4 * (lane >> 5)) * p.ldc * 2 + (lane & 31);
+        const int qoff = (HS * (lane >> 5)) * p.ldc * 2 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const size_t ro = (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc;
+                const size_t ro = (size_t)(i * 32 + acc_row<L16>(r)) * p.ldc;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float v = silu(acc[i][j][r] + bj[j]);
@@ -282,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
             if (EPI == xb::EPI_TANH_SCALE && p.expand) ocol = (n / p.nb) * (p.nb + 1) + 1 + n % p.nb;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = mw + i * 32 + acc_row<L16>(r) + HS * (lane >> 5);
                 if (m >= p.M) continue;
                 const float v = acc[i][j][r] + bias;
                 if (EPI == xb::EPI_BIAS_F32) {
@@ -397,6 +429,10 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
         la[ks] = (unsigned)((lane & 31) * 64 + (((2 * ks + (lane >> 5)) ^ ((lane >> 2) & 3)) * 16));
+    // S16 (the three-product arithmetic on v_mfma_f32_16x16x32_f16, see gemm4p_kernel): row (lane & 15) of a 16-row tile, the
+    // lane's eight k values are cell (lane >> 4) of the row
+    constexpr bool S16 = NSPLIT == 3 && XB_GEMM_S16 != 0;
+    const unsigned la16 = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16));
     const unsigned char *const fragA = smem_raw + wr * 2 * HTB;                              // SA_wr
     const unsigned char *const fragB = smem_raw + (2 + (wc >> 1)) * 2 * HTB + (wc & 1) * 4096;   // 64 rows of SB_(wc/2)
 
@@ -416,12 +452,13 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     // the LDS has the headroom, the register file has not)
     half8 ah[2][2], al[2][2], bh[2], bl[2];
     v8i aq[2], bq;                                    // NSPLIT == 2: q8 fragments (one 32-column block = the whole k-tile)
+    /* (S16: ah / al [i4 >> 1][i4 & 1] = 16-row tile i4 of the 64-row half, bh / bl [j2] = 16-column tile j2 of the 32 columns) */
 #define G8_READ_A(d, mh)                                                                                  \
     _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) {                                                    \
         const unsigned char *t_ = fragA + (d) * HTB + ((mh) * 2 + i2) * 2048;                         \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-            ah[i2][ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                   \
-            if (NSPLIT == 3) al[i2][ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + la[ks]);          \
+            ah[i2][ks] = *reinterpret_cast<const half8 *>(t_ + (S16 ? ks * 1024 + la16 : la[ks]));        \
+            if (NSPLIT == 3) al[i2][ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + (S16 ? ks * 1024 + la16 : la[ks])); \
         }                                                                                                 \
         if (NSPLIT == 2) {                                                                                \
             const v4i x_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqa[0]);                           \
@@ -433,8 +470,8 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     do {                                                                                                  \
         const unsigned char *t_ = fragB + (d) * HTB + (n) * 2048;                                     \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-            bh[ks] = *reinterpret_cast<const half8 *>(t_ + la[ks]);                                  \
-            if (NSPLIT == 3) bl[ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + la[ks]);         \
+            bh[ks] = *reinterpret_cast<const half8 *>(t_ + (S16 ? ks * 1024 + la16 : la[ks]));            \
+            if (NSPLIT == 3) bl[ks] = *reinterpret_cast<const half8 *>(t_ + PARTB + (S16 ? ks * 1024 + la16 : la[ks])); \
         }                                                                                                 \
         if (NSPLIT == 2) {                                                                                \
             const v4i x_ = *reinterpret_cast<const v4i *>(t_ + PARTB + lqb[0]);                           \
@@ -444,11 +481,19 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     } while (0)
 #define G8_F16(i2, ks, n, A_, B_)                                                                         \
     acc[(mh_) * 2 + (i2)][(n)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[(i2)][(ks)], B_[(ks)], acc[(mh_) * 2 + (i2)][(n)], 0, 0, 0)
+#define G8_S16(A_, B_, n)                                                                                 \
+    _Pragma("unroll") for (int i4 = 0; i4 < 4; ++i4)                                                      \
+        _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2)                                                  \
+            acc16[mh_ * 4 + i4][(n) * 2 + j2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[i4 >> 1][i4 & 1], B_[j2], acc16[mh_ * 4 + i4][(n) * 2 + j2], 0, 0, 0)
 #define G8_MFMA(mh, n)                                                                                    \
     do {                                                                                                  \
         constexpr int mh_ = (mh);                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                    \
-        if (NSPLIT == 2) {                                                                                \
+        if constexpr (S16) {                                                                              \
+            G8_S16(al, bh, n);                                                                            \
+            G8_S16(ah, bl, n);                                                                            \
+            G8_S16(ah, bh, n);                                                                            \
+        } else if (NSPLIT == 2) {                                                                                \
             G8_F16(0, 0, n, ah, bh);                                                                      \
             G8_F16(1, 0, n, ah, bh);                                                                      \
             _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) acc[mh_ * 2 + i2][(n)] =                     \
@@ -471,12 +516,19 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
     } while (0)
 
     floatx16 acc[4][2];
+    f32x4 acc16[8][4];                  // S16: 8 x 4 tiles of 16x16
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.0f;
 
     // ---- prologue: tile 0 in LDS, tile 1 in flight into the staging registers
 #pragma unroll
@@ -538,13 +590,15 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #undef G8_TILE
 #undef G8_MFMA
 #undef G8_F16
+#undef G8_S16
 #undef G8_READ_A
 #undef G8_READ_B
 
     // the epilogue's per-lane indices must not be computed (and kept in registers) ahead of the main loop
     int lane_e = lane, mw_e = m0 + wr * 128, nw_e = n0 + wc * 64;
     asm volatile("" : "+v"(lane_e), "+s"(mw_e), "+s"(nw_e));       // (the tile origin too: its divisions belong behind the loop)
-    gemm_epilogue<EPI>(p, acc, mw_e, nw_e, lane_e);
+    if constexpr (S16) acc16_lines(acc16, acc);
+    gemm_epilogue<EPI, S16>(p, acc, mw_e, nw_e, lane_e);
 }
 
 // ======================================================================================
@@ -682,14 +736,29 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         lqa[j] = (unsigned)((lane & 31) * 64 + (((2 * hs + j) ^ sw) * 16));      // q8 image, A role: lanes 0-31 h8, 32-63 l8
     }
     const int sca = 127 - p.a_exp - 11, scb = 127 - p.b_exp;      // E8M0 scale bytes: 2^-(a_exp + b_exp + 11) in all
+    // S16 (round 5): the three-product arithmetic on v_mfma_f32_16x16x32_f16 -- the same FLOPs per cycle as 32x32x16, but the chip,
+    // which lowers its clock under this kernel's load (1.6 GHz), holds a 13 % higher one on this shape (tools/ubench/mfma_shape.hip,
+    // profiles/r05_mfma_shape_ubench.txt; MI355X_MICROARCH.md, DVFS give-back item 7).  A wave's 128 x 64 outputs are 8 x 4 tiles of
+    // 16x16; a k-tile is ONE k-step of 32; A fragment of a 16-row tile: row (lane & 15), cell (lane >> 4) of the row (the LDS image
+    // and its swizzle are unchanged); the weight image's four pieces of a 32-row block are (hi, lo) x (rows 0-15, 16-31) with lane
+    // l = row (l & 15), k 8 (l >> 4) .. + 8 (xb_api.hip: fragment_major).
+    constexpr bool S16 = NSPLIT == 3 && XB_GEMM_S16 != 0;
+    const unsigned la16 = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ sw) * 16));
 
     floatx16 acc[4][2];
+    f32x4 acc16[8][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.0f;
 
 #define G4P_SB() __builtin_amdgcn_sched_barrier(0)
     constexpr bool G4P_LATE_A = XB_GEMM_LATE_A != 0 && NSPLIT != 2;
@@ -716,6 +785,26 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             acc[(ih) * 2 + i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_[i_], bq_, acc[(ih) * 2 + i_][j_], \
                                                                                    0, 0, 0, sca, 0, scb); \
         }
+    /* S16: fragments of the row tiles 2 q, 2 q + 1 of one part; the 24 MFMAs of a phase (rows 32 q .. 32 q + 31, all 64 columns): */
+    /* lo*hi, hi*lo, hi*hi per accumulator, eight accumulators between two uses of one                                          */
+#define G4P_RD16(d, sa, part, q)                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+        d[i_] = *reinterpret_cast<const half8 *>((sa) + (part) * PARTB + ((q) * 2 + i_) * 1024 + la16)
+#define G4P_M16(A_, q, bS, pc0)                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                        \
+            _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                    \
+                acc16[(q) * 2 + i_][2 * j_ + c_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(      \
+                    A_[i_], __builtin_bit_cast(half8, bS[j_][(pc0) + c_]), acc16[(q) * 2 + i_][2 * j_ + c_], 0, 0, 0)
+#define G4P_S16(AH_, AL_, q, bS)                                                                \
+    do {                                                                                        \
+        G4P_M16(AL_, q, bS, 0);                                                                 \
+        G4P_M16(AH_, q, bS, 2);                                                                 \
+        G4P_M16(AH_, q, bS, 0);                                                                 \
+    } while (0)
+#define G4P_WAIT8(n, bS)                                                                        \
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(bS[0][0]), "+v"(bS[1][0]), "+v"(bS[0][1]), "+v"(bS[1][1]), \
+                 "+v"(bS[0][2]), "+v"(bS[1][2]), "+v"(bS[0][3]), "+v"(bS[1][3]) : "i"(n))
 #define G4P_MFMA_BEGIN() do { G4P_SB(); __builtin_amdgcn_s_setprio(1); } while (0)
 #define G4P_MFMA_END() do { __builtin_amdgcn_s_setprio(0); G4P_SB(); } while (0)
 
@@ -765,6 +854,39 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_F16(g1, 1, bS, 1);                                                              \
             G4P_MFMA_END();                                                                     \
             G4P_LDB_GROUP(bS, b2, 1);                                                           \
+        } else if constexpr (S16) {                                                             \
+            /* four phases of 24 MFMAs; the A fragments of phases q and q + 1 in two register sets (x, y), those of phase q + 2  */ \
+            /* requested right behind the MFMAs of phase q; all eight B pieces are live until the last phase and are reloaded     */ \
+            /* for tile t + 2 behind it -- a whole k-tile (two, with the CU's other workgroup) ahead of their first use.  Issue   */ \
+            /* order per tile, hence the counted waits: A(t + 2) behind phase 0, B(t + 2) at the end.                             */ \
+            half8 xh[2], xl[2], yh[2], yl[2];                                                   \
+            constexpr int LA_ = G4P_LATE_A ? NA : 0;                                            \
+            G4P_RD16(xh, sa, 0, 0);                                                             \
+            G4P_RD16(xl, sa, 1, 0);                                                             \
+            G4P_RD16(yh, sa, 0, 1);                                                             \
+            G4P_RD16(yl, sa, 1, 1);                                                             \
+            G4P_WAIT8(INFL - 8 - LA_, bS);                                                      \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_S16(xh, xl, 0, bS);                                                             \
+            G4P_MFMA_END();                                                                     \
+            if constexpr (G4P_LATE_A) dma_a(t2_, nxt2);                                         \
+            G4P_RD16(xh, sa, 0, 2);                                                             \
+            G4P_RD16(xl, sa, 1, 2);                                                             \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_S16(yh, yl, 1, bS);                                                             \
+            G4P_MFMA_END();                                                                     \
+            G4P_RD16(yh, sa, 0, 3);                                                             \
+            G4P_RD16(yl, sa, 1, 3);                                                             \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_S16(xh, xl, 2, bS);                                                             \
+            G4P_MFMA_END();                                                                     \
+            G4P_MFMA_BEGIN();                                                                   \
+            G4P_S16(yh, yl, 3, bS);                                                             \
+            G4P_MFMA_END();                                                                     \
+            G4P_LDB_GROUP(bS, b2, 0);                                                           \
+            G4P_LDB_GROUP(bS, b2, 1);                                                           \
+            G4P_LDB_GROUP(bS, b2, 2);                                                           \
+            G4P_LDB_GROUP(bS, b2, 3);                                                           \
         } else {                                                                                \
             /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi.         */ \
             /* The A fragments of the two row-tile pairs (ih = 0: rows 0..63, ih = 1: rows 64..127) are software-pipelined by  */ \
@@ -883,6 +1005,10 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 #undef G4P_WAIT2
 #undef G4P_WAIT4
 #undef G4P_RD_H
+#undef G4P_RD16
+#undef G4P_M16
+#undef G4P_S16
+#undef G4P_WAIT8
 #undef G4P_RD_Q
 #undef G4P_F16
 #undef G4P_F8
@@ -892,7 +1018,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 
     int lane_e = lane, mw_e = m0, nw_e = n0 + wid * 64;
     asm volatile("" : "+v"(lane_e), "+s"(mw_e), "+s"(nw_e));
-    gemm_epilogue<EPI>(p, acc, mw_e, nw_e, lane_e);
+    if constexpr (S16) acc16_lines(acc16, acc);
+    gemm_epilogue<EPI, S16>(p, acc, mw_e, nw_e, lane_e);
 }
 
 template <int EPI, int NSPLIT>

@@ -128,10 +128,19 @@ struct GemmParams {
     int one_per_cu;              // gemm4p: 1 = at most one workgroup per CU (launches beside the recurrence)
     int sn;                      // gemm4p: N tiles per XCD super-tile (0 = the rule gemm_super_n; XB_GEMM_SN, experiments)
 };
+// XB_GEMM_S16 (compile time, both GEMM kernels and the host's weight images): 1 (default, round 5) = the three-product arithmetic
+// (nsplit 3) runs on v_mfma_f32_16x16x32_f16 -- per accumulator and k-tile of 32: lo*hi, hi*lo, hi*hi --, 0 = on 32x32x16 (per
+// k-step of 16) as in rounds 1-4.  The two sum the same products in different orders (low-bit differences); the chip holds a
+// 13 % higher clock on the 16x16x32 shape (profiles/r05_mfma_shape_ubench.txt).
+#ifndef XB_GEMM_S16
+#define XB_GEMM_S16 1
+#endif
 // pieces per 32-row block and k-tile of the fragment-major image for a given nsplit (lane l = 32 h + r holds row r):
 //   piece 0, 1: the 8 fp16 `hi` values of columns 32 kt + 16 ks + 8 h .. + 8, ks = 0, 1
 //   nsplit 3: piece 2, 3: the same of `lo`;   nsplit 2: pieces 2, 3 = bytes 0..15 / 16..31 of the q8 half the B role reads
 //   (h = 0: the l8 codes of the 32 columns, h = 1: the h8 codes)
+//   nsplit 3 with XB_GEMM_S16: lane l = 16 g + r; piece 2 part + c (part 0 = hi, 1 = lo; c = 0, 1) holds row 16 c + r's eight
+//   values of columns 32 kt + 8 g .. + 8
 inline int gemm4_pieces(int nsplit) { return nsplit == 1 ? 2 : 4; }
 // gin layout (input projection of an LSTM layer, written by the GEMM, read by lstm_kernel): row m = t * n + chunk, column
 // c = unit * 4 + gate.  Stored member-major, [t][c / 128][chunk][c % 128]: the 64 chunks x 128 gate columns a recurrence
