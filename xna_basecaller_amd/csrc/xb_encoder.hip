@@ -636,6 +636,9 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #ifndef XB_GEMM_LATE_A           // 1: (three- and one-product kernels) a k-tile's LDS-DMA requests behind its first MFMA group (A/B builds)
 #define XB_GEMM_LATE_A 1
 #endif
+#ifndef XB_GEMM_S16_V            // A/B builds of the 16x16x32 loop: bit 0 = lo weight pieces reloaded behind their last product (the prologue's order
+#define XB_GEMM_S16_V 1          // follows), bit 1 = the second A fragment set requested behind the first product group of phase 0
+#endif
 #ifndef XB_GEMM_DMA_ASM          // 1: gemm4p_kernel's A-tile LDS-DMA requests as inline asm (see dma_a); 0: the builtin (A/B builds)
 #define XB_GEMM_DMA_ASM 1
 #endif
@@ -861,32 +864,62 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             /* order per tile, hence the counted waits: A(t + 2) behind phase 0, B(t + 2) at the end.                             */ \
             half8 xh[2], xl[2], yh[2], yl[2];                                                   \
             constexpr int LA_ = G4P_LATE_A ? NA : 0;                                            \
-            G4P_RD16(xh, sa, 0, 0);                                                             \
             G4P_RD16(xl, sa, 1, 0);                                                             \
-            G4P_RD16(yh, sa, 0, 1);                                                             \
-            G4P_RD16(yl, sa, 1, 1);                                                             \
+            G4P_RD16(xh, sa, 0, 0);                                                             \
+            if constexpr (!(XB_GEMM_S16_V & 2)) {                                               \
+                G4P_RD16(yl, sa, 1, 1);                                                         \
+                G4P_RD16(yh, sa, 0, 1);                                                         \
+            }                                                                                   \
             G4P_WAIT8(INFL - 8 - LA_, bS);                                                      \
-            G4P_MFMA_BEGIN();                                                                   \
-            G4P_S16(xh, xl, 0, bS);                                                             \
-            G4P_MFMA_END();                                                                     \
+            if constexpr (XB_GEMM_S16_V & 2) {                                                  \
+                /* the second set's reads behind the first product group of phase 0 */          \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_M16(xl, 0, bS, 0);                                                          \
+                G4P_MFMA_END();                                                                 \
+                G4P_RD16(yl, sa, 1, 1);                                                         \
+                G4P_RD16(yh, sa, 0, 1);                                                         \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_M16(xh, 0, bS, 2);                                                          \
+                G4P_M16(xh, 0, bS, 0);                                                          \
+                G4P_MFMA_END();                                                                 \
+            } else {                                                                            \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_S16(xh, xl, 0, bS);                                                         \
+                G4P_MFMA_END();                                                                 \
+            }                                                                                   \
             if constexpr (G4P_LATE_A) dma_a(t2_, nxt2);                                         \
-            G4P_RD16(xh, sa, 0, 2);                                                             \
             G4P_RD16(xl, sa, 1, 2);                                                             \
+            G4P_RD16(xh, sa, 0, 2);                                                             \
             G4P_MFMA_BEGIN();                                                                   \
             G4P_S16(yh, yl, 1, bS);                                                             \
             G4P_MFMA_END();                                                                     \
-            G4P_RD16(yh, sa, 0, 3);                                                             \
             G4P_RD16(yl, sa, 1, 3);                                                             \
+            G4P_RD16(yh, sa, 0, 3);                                                             \
             G4P_MFMA_BEGIN();                                                                   \
             G4P_S16(xh, xl, 2, bS);                                                             \
             G4P_MFMA_END();                                                                     \
-            G4P_MFMA_BEGIN();                                                                   \
-            G4P_S16(yh, yl, 3, bS);                                                             \
-            G4P_MFMA_END();                                                                     \
-            G4P_LDB_GROUP(bS, b2, 0);                                                           \
-            G4P_LDB_GROUP(bS, b2, 1);                                                           \
-            G4P_LDB_GROUP(bS, b2, 2);                                                           \
-            G4P_LDB_GROUP(bS, b2, 3);                                                           \
+            if constexpr (XB_GEMM_S16_V & 1) {                                                  \
+                /* the lo pieces are reloaded behind their last product, the hi pieces at the end */ \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_M16(yl, 3, bS, 0);                                                          \
+                G4P_M16(yh, 3, bS, 2);                                                          \
+                G4P_MFMA_END();                                                                 \
+                G4P_LDB_GROUP(bS, b2, 2);                                                       \
+                G4P_LDB_GROUP(bS, b2, 3);                                                       \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_M16(yh, 3, bS, 0);                                                          \
+                G4P_MFMA_END();                                                                 \
+                G4P_LDB_GROUP(bS, b2, 0);                                                       \
+                G4P_LDB_GROUP(bS, b2, 1);                                                       \
+            } else {                                                                            \
+                G4P_MFMA_BEGIN();                                                               \
+                G4P_S16(yh, yl, 3, bS);                                                         \
+                G4P_MFMA_END();                                                                 \
+                G4P_LDB_GROUP(bS, b2, 0);                                                       \
+                G4P_LDB_GROUP(bS, b2, 1);                                                       \
+                G4P_LDB_GROUP(bS, b2, 2);                                                       \
+                G4P_LDB_GROUP(bS, b2, 3);                                                       \
+            }                                                                                   \
         } else {                                                                                \
             /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi.         */ \
             /* The A fragments of the two row-tile pairs (ih = 0: rows 0..63, ih = 1: rows 64..127) are software-pipelined by  */ \
@@ -970,6 +1003,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         dma_a(0, 0);
         if constexpr (NSPLIT == 2) {
             G4P_LDB_GROUP(bE, b0, 0); G4P_LDB_GROUP(bE, b0, 2); G4P_LDB_GROUP(bE, b0, 3); G4P_LDB_GROUP(bE, b0, 1);
+        } else if constexpr (S16 && (XB_GEMM_S16_V & 1)) {
+            G4P_LDB_GROUP(bE, b0, 2); G4P_LDB_GROUP(bE, b0, 3); G4P_LDB_GROUP(bE, b0, 0); G4P_LDB_GROUP(bE, b0, 1);
         } else {
             G4P_LDB_GROUP(bE, b0, 0); if (NSPLIT == 3) G4P_LDB_GROUP(bE, b0, 2);
             G4P_LDB_GROUP(bE, b0, 1); if (NSPLIT == 3) G4P_LDB_GROUP(bE, b0, 3);
@@ -977,6 +1012,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         dma_a(t1, 1);
         if constexpr (NSPLIT == 2) {
             G4P_LDB_GROUP(bO, b1, 0); G4P_LDB_GROUP(bO, b1, 2); G4P_LDB_GROUP(bO, b1, 3); G4P_LDB_GROUP(bO, b1, 1);
+        } else if constexpr (S16 && (XB_GEMM_S16_V & 1)) {
+            G4P_LDB_GROUP(bO, b1, 2); G4P_LDB_GROUP(bO, b1, 3); G4P_LDB_GROUP(bO, b1, 0); G4P_LDB_GROUP(bO, b1, 1);
         } else {
             G4P_LDB_GROUP(bO, b1, 0); if (NSPLIT == 3) G4P_LDB_GROUP(bO, b1, 2);
             G4P_LDB_GROUP(bO, b1, 1); if (NSPLIT == 3) G4P_LDB_GROUP(bO, b1, 3);
