@@ -1777,5 +1777,15 @@ XB_API int xb_debug_lstm_stamps(xb_ctx *ctx, unsigned long long out[10], int res
     return XB_OK;
 }
 #endif
+#ifdef XB_GEMM_STAMPS
+// diagnostic build only: per-phase cycle sums of gemm4p_kernel<*, 3> (xb_encoder.hip, g_gemm_stamps)
+XB_API int xb_debug_gemm_stamps(xb_ctx *ctx, unsigned long long out[8], int reset)
+{
+    if (!ctx) return XB_ERR_INVALID;
+    if (int rc = sync_all(ctx)) return rc;
+    xb::gemm_read_stamps(out, reset != 0);
+    return XB_OK;
+}
+#endif
 
 }  // extern "C"

@@ -199,6 +199,9 @@ __device__ __forceinline__ void gemm_epilogue(const xb::GemmParams &p, const flo
 {
     constexpr int HS = L16 ? 8 : 4;              // rows between the two lane halves
     if (mw >= p.M || nw >= p.Nn) return;         // a wave wholly outside the matrix (edge tiles)
+#if defined(XB_GEMM_ABL_EPI)                     // timing-only builds (WRONG results): no epilogue at all
+    if (p.M > 0) return;
+#endif
     float bj[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -636,6 +639,9 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #ifndef XB_GEMM_LATE_A           // 1: (three- and one-product kernels) a k-tile's LDS-DMA requests behind its first MFMA group (A/B builds)
 #define XB_GEMM_LATE_A 1
 #endif
+#ifndef XB_GEMM_ABL              // timing-only builds (WRONG results unless 0): bit 0 = every weight reload reads k-tile 0 again (L1-resident), bit 1 = every
+#define XB_GEMM_ABL 0            // A-tile request reads k-tile 0 again: what the loop's L2 -> CU traffic costs, instruction stream unchanged
+#endif
 #ifndef XB_GEMM_S16_V            // A/B builds of the 16x16x32 loop: bit 0 = lo weight pieces reloaded behind their last product (the prologue's order
 #define XB_GEMM_S16_V 1          // follows), bit 1 = the second A fragment set requested behind the first product group of phase 0
 #endif
@@ -643,6 +649,15 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #define XB_GEMM_DMA_ASM 1
 #endif
 constexpr int G4_BM = 128, G4_BN = 256, G4_THREADS = 256;
+#ifdef XB_GEMM_STAMPS
+// diagnostic build only: cycle sums over wave 0 of every gemm4p_kernel<*, 3> workgroup, by phase -- 0 prologue (kernel start to the first
+// k-tile), 1 top of a k-tile (the tile's A requests landed + barrier), 2 weight pieces landed (+ the first fragment reads issued),
+// 3 the tile's MFMA phases, 4 loop end to kernel end (drain + epilogue); [6] = workgroups, [7] = k-tiles
+__device__ unsigned long long g_gemm_stamps[8];
+#define G4P_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[(i)] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define G4P_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool gemm4_tile_origin(const xb::GemmParams &p, int &m0, int &n0)
 {
@@ -676,6 +691,9 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     int m0, n0;
     if (!gemm4_tile_origin(p, m0, n0)) return;
     const int nk = p.K / GBK;
+#ifdef XB_GEMM_STAMPS
+    unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[5] = {0, 0, 0, 0, 0};
+#endif
 
     // ---- A: lane i of wave w fills, per part, LDS cells of rows 16 w + (i >> 2) and 64 + that; cell (i & 3) of a row holds
     //      source cell (i & 3) ^ ((row >> 2) & 3).  Rows past the matrix end are clamped to the last row.
@@ -816,12 +834,15 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 #define G4P_TILE(bS, t)                                                                         \
     do {                                                                                        \
         const unsigned char *const sa = smem_raw + cur * STB;                                   \
-        const int t2_ = (t) + 2 < nk ? (t) + 2 : nk - 1;                                        \
-        const unsigned char *const b2 = tB + (size_t)t2_ * bks;                                 \
+        const int t2r_ = (t) + 2 < nk ? (t) + 2 : nk - 1;                                       \
+        const int t2_ = (XB_GEMM_ABL & 2) ? 0 : t2r_;       /* timing-only builds, see XB_GEMM_ABL */ \
+        const unsigned char *const b2 = tB + (size_t)((XB_GEMM_ABL & 1) ? 0 : t2r_) * bks;      \
+        if ((t) == 0) G4P_STAMP(0);                                                             \
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NB + NA) : "memory");                      \
         G4P_SB();                                                                               \
         __builtin_amdgcn_s_barrier();                                                           \
         G4P_SB();                                                                               \
+        G4P_STAMP(1);                                                                           \
         if constexpr (!G4P_LATE_A) dma_a(t2_, nxt2);                                            \
         if constexpr (NSPLIT == 2) {                                                            \
             /* fragments of the NEXT group are requested ahead of the last four MFMAs of the current one: hipcc forgets its */ \
@@ -871,6 +892,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 G4P_RD16(yh, sa, 0, 1);                                                         \
             }                                                                                   \
             G4P_WAIT8(INFL - 8 - LA_, bS);                                                      \
+            G4P_STAMP(2);                                                                       \
             if constexpr (XB_GEMM_S16_V & 2) {                                                  \
                 /* the second set's reads behind the first product group of phase 0 */          \
                 G4P_MFMA_BEGIN();                                                               \
@@ -973,6 +995,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             }                                                                                   \
         }                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+        G4P_STAMP(3);                                                                           \
         { const int c_ = cur; cur = nxt1; nxt1 = nxt2; nxt2 = c_; }                             \
     } while (0)
 
@@ -995,6 +1018,11 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         return;
     }
 
+    // (Round 5, measured on real data with cycle stamps -- tools/gemm_stamps.py, profiles/r05_gemm_stamps.txt: a workgroup spends 26 % of its life
+    //  outside its MFMA phases (prologue 4, k-tile waits 13, drain + epilogue 9) and its MFMA phases take 1.92x their own pipe time: the
+    //  pipe is saturated while both workgroups of a CU are in them.  Starting the workgroup in the CU's second wave slot (HW_REG_HW_ID) a
+    //  quarter or half a workgroup life late changes neither the stamps nor the time (54.1 vs 53.2 ms per five input GEMMs): the two are
+    //  not in lock-step, their waits coincide because the memory side makes them wait at the same moments.)
     // ---- prologue: A(0) B(0) A(1) B(1) in the loop's issue order
     int cur = 0, nxt1 = 1, nxt2 = 2;
     {
@@ -1057,6 +1085,18 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     asm volatile("" : "+v"(lane_e), "+s"(mw_e), "+s"(nw_e));
     if constexpr (S16) acc16_lines(acc16, acc);
     gemm_epilogue<EPI, S16>(p, acc, mw_e, nw_e, lane_e);
+#ifdef XB_GEMM_STAMPS
+    if (NSPLIT == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have left the wave
+        G4P_STAMP(4);
+        if (tid == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_stamps[i], st_acc[i]);
+            atomicAdd(&g_gemm_stamps[5], (unsigned long long)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u));   // workgroups in an odd wave slot
+            atomicAdd(&g_gemm_stamps[6], 1ull);
+            atomicAdd(&g_gemm_stamps[7], (unsigned long long)nk);
+        }
+    }
+#endif
 }
 
 template <int EPI, int NSPLIT>
@@ -1114,6 +1154,17 @@ hipError_t launch_gemm_epi(const xb::GemmParams &p, hipStream_t stream)
 
 
 namespace xb {
+
+#ifdef XB_GEMM_STAMPS
+void gemm_read_stamps(unsigned long long out[8], bool reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof z);
+    }
+}
+#endif
 
 hipError_t launch_conv_front(const ConvFrontParams &p, hipStream_t stream)
 {

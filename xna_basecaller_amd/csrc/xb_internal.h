@@ -208,6 +208,7 @@ int lstm_group_chunks();
 bool lstm_supported_features(int F);
 #ifdef XB_LSTM_STAMPS
 void lstm_read_stamps(unsigned long long out[10], bool reset);   // diagnostic build only
+void gemm_read_stamps(unsigned long long out[8], bool reset);    // diagnostic build only (XB_GEMM_STAMPS)
 #endif
 
 }  // namespace xb
