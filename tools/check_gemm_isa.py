@@ -23,7 +23,8 @@ def main():
     bad = 0
     for m in re.finditer(r"^(_ZN12_GLOBAL__N_113gemm4p_kernelILi(\d)ELi(\d)EEEvN2xb10GemmParamsE):[^\n]*\n(.*?)s_endpgm", text, re.M | re.S):
         name, epi, nsplit, body = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4)
-        want_mfma = {1: 32, 2: 48, 3: 96}[nsplit]              # per two k-tiles (the loop is unrolled by two)
+        s16 = nsplit == 3 and "v_mfma_f32_16x16x32_f16" in body   # XB_GEMM_S16: the three-product arithmetic on 16x16x32 (two counted waits per k-tile)
+        want_mfma = {1: 32, 2: 48, 3: 192 if s16 else 96}[nsplit]   # per two k-tiles (the loop is unrolled by two)
         want_loads = {1: 8, 2: 16, 3: 16}[nsplit]
         blocks = re.split(r"^\.LBB\d+_\d+:.*$", body, flags=re.M)
         loops = [b for b in blocks if b.count("v_mfma") == want_mfma]
@@ -34,7 +35,7 @@ def main():
             b = loops[0]
             waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", b)]
             moves, loads, branches = b.count("v_mov"), b.count("global_load_dwordx4"), b.count("s_cbranch")
-            ok = ok and moves == 0 and loads == want_loads and branches <= 2 and all(w >= 4 for w in waits) and len(waits) in (6, 8)
+            ok = ok and moves == 0 and loads == want_loads and branches <= 2 and all(w >= 4 for w in waits) and len(waits) in ((4,) if s16 else (6, 8))
             info = "v_mov %d, loads %d, branches %d, vmcnt waits %s, scratch %d" % (moves, loads, branches, waits, scratch)
         print("gemm4p_kernel<%d, %d>: %s  %s" % (epi, nsplit, "ok " if ok else "BAD", info))
         bad += 0 if ok else 1
