@@ -200,8 +200,10 @@ def test_four_thousand_short_reads_in_one_multi_read_fast5(tmp_path):
     by_id = {r.read_id: r for r in xreads.get_reads(str(dn), n_proc=procs)}
     _same_reads(pooled, [by_id[r.read_id] for r in pooled])
     print("fast5: %.0f reads/s with %d workers, %.0f reads/s serial" % (best, procs, serial_rate))
-    assert serial_rate >= 300, serial_rate                     # round 4: 47-95 reads/s
-    assert best >= 1500 * procs / 8.0, (best, procs)           # round 4: 71 reads/s with 8 workers (a cold first pass here: ~2 200)
+    # floors an order of magnitude above round 4's reader and well below what an idle machine gives (4 500 - 6 000 pooled, ~1 100
+    # serial): they fail on a per-read re-walk of the container, not on a test host that is busy with other work
+    assert serial_rate >= 200, serial_rate                     # round 4: 47-95 reads/s
+    assert best >= 700 * procs / 8.0, (best, procs)            # round 4: 71 reads/s with 8 workers
     xreads.close_containers()
 
 
