@@ -23,7 +23,8 @@ def main():
     bad = 0
     for m in re.finditer(r"^(_ZN12_GLOBAL__N_113gemm4p_kernelILi(\d)ELi(\d)EEEvN2xb10GemmParamsE):[^\n]*\n(.*?)s_endpgm", text, re.M | re.S):
         name, epi, nsplit, body = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4)
-        s16 = nsplit == 3 and "v_mfma_f32_16x16x32_f16" in body   # XB_GEMM_S16: the three-product arithmetic on 16x16x32 (two counted waits per k-tile)
+        s16 = nsplit == 3 and "v_mfma_f32_16x16x32_f16" in body   # XB_GEMM_S16: the three-product arithmetic on 16x16x32 (two counted waits per k-tile:
+        # B(t) landed in front of phase 0 and -- XB_GEMM_XTILE -- A(t + 1) landed in front of the barrier between phases 2 and 3, vmcnt(12) both)
         want_mfma = {1: 32, 2: 48, 3: 192 if s16 else 96}[nsplit]   # per two k-tiles (the loop is unrolled by two)
         want_loads = {1: 8, 2: 16, 3: 16}[nsplit]
         blocks = re.split(r"^\.LBB\d+_\d+:.*$", body, flags=re.M)

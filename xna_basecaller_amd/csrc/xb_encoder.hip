@@ -645,6 +645,12 @@ __global__ __launch_bounds__(GTHREADS) void gemm8r_kernel(xb::GemmParams p)
 #ifndef XB_GEMM_S16_V            // A/B builds of the 16x16x32 loop: bit 0 = lo weight pieces reloaded behind their last product (the prologue's order
 #define XB_GEMM_S16_V 1          // follows), bit 1 = the second A fragment set requested behind the first product group of phase 0
 #endif
+#ifndef XB_GEMM_TAIL             // 1 (round 5): the requests the branch-free k loop issues past the last k-tile (two tiles' worth per workgroup, so that
+#define XB_GEMM_TAIL 1           // every counted wait keeps its value) fetch one cache line each instead of the last tile again; 0: rounds 3-4 (A/B builds)
+#endif
+#ifndef XB_GEMM_XTILE            // 1 (round 5, the 16x16x32 loop): the k-tile's barrier sits between its third and fourth MFMA phase instead of at its top, and
+#define XB_GEMM_XTILE 1          // the first fragments of tile t + 1 are requested behind it -- their LDS latency runs under the fourth phase's 24 MFMAs; 0: rounds 3-4
+#endif
 #ifndef XB_GEMM_DMA_ASM          // 1: gemm4p_kernel's A-tile LDS-DMA requests as inline asm (see dma_a); 0: the builtin (A/B builds)
 #define XB_GEMM_DMA_ASM 1
 #endif
@@ -710,9 +716,12 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     //  book them as LDS events: with the builtin every wait for an A fragment in the k loop is lgkmcnt(0), i.e. all eight fragment
     //  reads of a k-step are waited for before its first MFMA; hidden from the compiler it counts, and the MFMAs on the first two
     //  row tiles start while the other two tiles' fragments are still in flight)
-    auto dma_a = [&](int t, int stage) {
+    // `live` false (round 5, XB_GEMM_TAIL): a request past the last k-tile -- issued all the same so that every counted wait keeps
+    // its value, but with every lane on the tile's first 16 bytes: one cache line through the vector-memory path instead of sixteen
+    auto dma_a = [&](int t, int stage, bool live = true) {
         const size_t kb = (size_t)t * (GBK * 2);
         unsigned char *dst = smem_raw + stage * STB + wid * 1024;
+        const unsigned ol[2] = {live ? offs[0] : 0u, live ? offs[1] : 0u};
 #pragma unroll
         for (int part = 0; part < NPA; ++part)
 #pragma unroll
@@ -721,10 +730,10 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 const unsigned m0v = __builtin_amdgcn_readfirstlane(
                     (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(dst + part * PARTB + h * 4096));
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             ::"v"(offs[h]), "s"((part ? tA_lo : tA_hi) + kb), "s"(m0v) : "memory", "m0");
+                             ::"v"(ol[h]), "s"((part ? tA_lo : tA_hi) + kb), "s"(m0v) : "memory", "m0");
 #else
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)((part ? tA_lo : tA_hi) + kb + offs[h]),
+                    (const __attribute__((address_space(1))) void *)((part ? tA_lo : tA_hi) + kb + ol[h]),
                     (__attribute__((address_space(3))) void *)(dst + part * PARTB + h * 4096), 16, 0, 0);
 #endif
             }
@@ -734,16 +743,17 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     const unsigned boff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(n0 + wid * 64) >> 5) * NPC * 1024u));
     const unsigned char *const tB = p.b4 + boff;       // wave-uniform by construction: an SGPR pair for the asm loads
     const size_t bks = p.b4_kstride;
-    const unsigned voff0 = (unsigned)lane * 16, voff1 = voff0 + NPC * 1024;
+    const unsigned voff0 = (unsigned)lane * 16;       // the wave's second 32-row block is NPC KiB further on: in the (scalar) base
     u32x4 bE[2][NPC], bO[2][NPC];               // even / odd k-tile
     // (default cache policy: with the nt bit -- the weights bypassing the L1 -- the five input GEMMs take 65 instead of 47 ms)
-#define G4P_LDB(dst, base, j, pc)                                                               \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"((j) ? voff1 : voff0), "s"(base), "i"((pc) * 1024))
-#define G4P_LDB_GROUP(bS, base, pc)                                                             \
+#define G4P_LDB(dst, vo, base, j, pc)                                                           \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo), "s"((base) + (j) * (NPC * 1024)), "i"((pc) * 1024))
+#define G4P_LDB_GROUP_V(bS, vo, base, pc)                                                       \
     do {                                                                                        \
-        G4P_LDB(bS[0][(pc)], base, 0, pc);                                                      \
-        G4P_LDB(bS[1][(pc)], base, 1, pc);                                                      \
+        G4P_LDB(bS[0][(pc)], vo, base, 0, pc);                                                  \
+        G4P_LDB(bS[1][(pc)], vo, base, 1, pc);                                                  \
     } while (0)
+#define G4P_LDB_GROUP(bS, base, pc) G4P_LDB_GROUP_V(bS, voff0, base, pc)
     // counted waits that also make the named registers "written here" for the compiler
 #define G4P_WAIT2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(n))
 #define G4P_WAIT4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(n))
@@ -766,6 +776,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
     constexpr bool S16 = NSPLIT == 3 && XB_GEMM_S16 != 0;
     const unsigned la16 = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ sw) * 16));
 
+    constexpr bool XT = S16 && XB_GEMM_XTILE != 0 && (XB_GEMM_S16_V & 2) == 0;
+    half8 xh[2], xl[2];                         // S16: the A fragments of phase 0 / 2 (XT: requested one tile ahead)
     floatx16 acc[4][2];
     f32x4 acc16[8][4];
 #pragma unroll
@@ -837,13 +849,18 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         const int t2r_ = (t) + 2 < nk ? (t) + 2 : nk - 1;                                       \
         const int t2_ = (XB_GEMM_ABL & 2) ? 0 : t2r_;       /* timing-only builds, see XB_GEMM_ABL */ \
         const unsigned char *const b2 = tB + (size_t)((XB_GEMM_ABL & 1) ? 0 : t2r_) * bks;      \
+        /* the last two tiles have no tile t + 2: their requests keep the counts and fetch one line each (see dma_a) */ \
+        const bool live_ = XB_GEMM_TAIL == 0 || (t) + 2 < nk;                                   \
+        const unsigned vb_ = live_ ? voff0 : 0u;                                                \
         if ((t) == 0) G4P_STAMP(0);                                                             \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NB + NA) : "memory");                      \
-        G4P_SB();                                                                               \
-        __builtin_amdgcn_s_barrier();                                                           \
-        G4P_SB();                                                                               \
-        G4P_STAMP(1);                                                                           \
-        if constexpr (!G4P_LATE_A) dma_a(t2_, nxt2);                                            \
+        if constexpr (!XT) {                                                                    \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NB + NA) : "memory");                  \
+            G4P_SB();                                                                           \
+            __builtin_amdgcn_s_barrier();                                                       \
+            G4P_SB();                                                                           \
+            G4P_STAMP(1);                                                                       \
+        }                                                                                       \
+        if constexpr (!G4P_LATE_A) dma_a(t2_, nxt2, live_);                                            \
         if constexpr (NSPLIT == 2) {                                                            \
             /* fragments of the NEXT group are requested ahead of the last four MFMAs of the current one: hipcc forgets its */ \
             /* lgkmcnt bookkeeping at every asm statement and waits lgkmcnt(0) behind it, which is free once they landed */ \
@@ -860,7 +877,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_MFMA_BEGIN();                                                                   \
             G4P_F16(h1, 1, bS, 0);                                                              \
             G4P_MFMA_END();                                                                     \
-            G4P_LDB_GROUP(bS, b2, 0);                                                           \
+            G4P_LDB_GROUP_V(bS, vb_, b2, 0);                                                           \
             G4P_WAIT4(INFL - 4, bS[0][2], bS[0][3], bS[1][2], bS[1][3]);                        \
             G4P_MFMA_BEGIN();                                                                   \
             G4P_F8(q0, 0, bS);                                                                  \
@@ -870,23 +887,29 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_MFMA_BEGIN();                                                                   \
             G4P_F8(q1, 1, bS);                                                                  \
             G4P_MFMA_END();                                                                     \
-            G4P_LDB_GROUP(bS, b2, 2);                                                           \
-            G4P_LDB_GROUP(bS, b2, 3);                                                           \
+            G4P_LDB_GROUP_V(bS, vb_, b2, 2);                                                           \
+            G4P_LDB_GROUP_V(bS, vb_, b2, 3);                                                           \
             G4P_WAIT2(INFL - 2, bS[0][1], bS[1][1]);                                            \
             G4P_MFMA_BEGIN();                                                                   \
             G4P_F16(g0, 0, bS, 1);                                                              \
             G4P_F16(g1, 1, bS, 1);                                                              \
             G4P_MFMA_END();                                                                     \
-            G4P_LDB_GROUP(bS, b2, 1);                                                           \
+            G4P_LDB_GROUP_V(bS, vb_, b2, 1);                                                           \
         } else if constexpr (S16) {                                                             \
             /* four phases of 24 MFMAs; the A fragments of phases q and q + 1 in two register sets (x, y), those of phase q + 2  */ \
             /* requested right behind the MFMAs of phase q; all eight B pieces are live until the last phase and are reloaded     */ \
             /* for tile t + 2 behind it -- a whole k-tile (two, with the CU's other workgroup) ahead of their first use.  Issue   */ \
             /* order per tile, hence the counted waits: A(t + 2) behind phase 0, B(t + 2) at the end.                             */ \
-            half8 xh[2], xl[2], yh[2], yl[2];                                                   \
+            /* XT (round 5): the fragments of phase 0 (xh, xl: loop-carried) were requested behind the barrier inside the      */ \
+            /* previous tile (the prologue, for tile 0); that barrier -- every wave has A(t + 1) landed, vmcnt(NB + NA): B(t + 1) */ \
+            /* and A(t + 2) are younger, and has finished reading tile t -- sits between phases 2 and 3.  The order of the     */ \
+            /* vector-memory instructions, hence every other counted wait, is unchanged.                                         */ \
+            half8 yh[2], yl[2];                                                                 \
             constexpr int LA_ = G4P_LATE_A ? NA : 0;                                            \
-            G4P_RD16(xl, sa, 1, 0);                                                             \
-            G4P_RD16(xh, sa, 0, 0);                                                             \
+            if constexpr (!XT) {                                                                \
+                G4P_RD16(xl, sa, 1, 0);                                                         \
+                G4P_RD16(xh, sa, 0, 0);                                                         \
+            }                                                                                   \
             if constexpr (!(XB_GEMM_S16_V & 2)) {                                               \
                 G4P_RD16(yl, sa, 1, 1);                                                         \
                 G4P_RD16(yh, sa, 0, 1);                                                         \
@@ -909,7 +932,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 G4P_S16(xh, xl, 0, bS);                                                         \
                 G4P_MFMA_END();                                                                 \
             }                                                                                   \
-            if constexpr (G4P_LATE_A) dma_a(t2_, nxt2);                                         \
+            if constexpr (G4P_LATE_A) dma_a(t2_, nxt2, live_);                                         \
             G4P_RD16(xl, sa, 1, 2);                                                             \
             G4P_RD16(xh, sa, 0, 2);                                                             \
             G4P_MFMA_BEGIN();                                                                   \
@@ -920,27 +943,38 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_MFMA_BEGIN();                                                                   \
             G4P_S16(xh, xl, 2, bS);                                                             \
             G4P_MFMA_END();                                                                     \
+            if constexpr (XT) {                                                                 \
+                G4P_STAMP(3);                                                                   \
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"i"(NB + NA) : "memory"); \
+                G4P_SB();                                                                       \
+                __builtin_amdgcn_s_barrier();                                                   \
+                G4P_SB();                                                                       \
+                G4P_STAMP(1);                                                                   \
+                const unsigned char *const sn = smem_raw + nxt1 * STB;                          \
+                G4P_RD16(xl, sn, 1, 0);                                                         \
+                G4P_RD16(xh, sn, 0, 0);                                                         \
+            }                                                                                   \
             if constexpr (XB_GEMM_S16_V & 1) {                                                  \
                 /* the lo pieces are reloaded behind their last product, the hi pieces at the end */ \
                 G4P_MFMA_BEGIN();                                                               \
                 G4P_M16(yl, 3, bS, 0);                                                          \
                 G4P_M16(yh, 3, bS, 2);                                                          \
                 G4P_MFMA_END();                                                                 \
-                G4P_LDB_GROUP(bS, b2, 2);                                                       \
-                G4P_LDB_GROUP(bS, b2, 3);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 2);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 3);                                                       \
                 G4P_MFMA_BEGIN();                                                               \
                 G4P_M16(yh, 3, bS, 0);                                                          \
                 G4P_MFMA_END();                                                                 \
-                G4P_LDB_GROUP(bS, b2, 0);                                                       \
-                G4P_LDB_GROUP(bS, b2, 1);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 0);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 1);                                                       \
             } else {                                                                            \
                 G4P_MFMA_BEGIN();                                                               \
                 G4P_S16(yh, yl, 3, bS);                                                         \
                 G4P_MFMA_END();                                                                 \
-                G4P_LDB_GROUP(bS, b2, 0);                                                       \
-                G4P_LDB_GROUP(bS, b2, 1);                                                       \
-                G4P_LDB_GROUP(bS, b2, 2);                                                       \
-                G4P_LDB_GROUP(bS, b2, 3);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 0);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 1);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 2);                                                       \
+                G4P_LDB_GROUP_V(bS, vb_, b2, 3);                                                       \
             }                                                                                   \
         } else {                                                                                \
             /* NSPLIT 3: per k-step lo*hi, hi*lo, hi*hi (pieces: 0, 1 = hi of k-step 0, 1; 2, 3 = lo); NSPLIT 1: hi*hi.         */ \
@@ -972,7 +1006,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 G4P_F16(ah0, 0, bS, ks);                                                        \
                 G4P_MFMA_END();                                                                 \
                 if (ks == 0) {                                                                  \
-                    if constexpr (G4P_LATE_A) dma_a(t2_, nxt2);                                 \
+                    if constexpr (G4P_LATE_A) dma_a(t2_, nxt2, live_);                                 \
                     G4P_RD_H(ah0, sa, 0, 0, 1);                                                 \
                     if (NSPLIT == 3) G4P_RD_H(al0, sa, 1, 0, 1);                                \
                 }                                                                               \
@@ -986,15 +1020,15 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
                 if (ks == 0) {                                                                  \
                     G4P_RD_H(ah1, sa, 0, 1, 1);                                                 \
                     if (NSPLIT == 3) G4P_RD_H(al1, sa, 1, 1, 1);                                \
-                    G4P_LDB_GROUP(bS, b2, 0);                                                   \
-                    if (NSPLIT == 3) G4P_LDB_GROUP(bS, b2, 2);                                  \
+                    G4P_LDB_GROUP_V(bS, vb_, b2, 0);                                                   \
+                    if (NSPLIT == 3) G4P_LDB_GROUP_V(bS, vb_, b2, 2);                                  \
                 } else {                                                                        \
-                    G4P_LDB_GROUP(bS, b2, 1);                                                   \
-                    if (NSPLIT == 3) G4P_LDB_GROUP(bS, b2, 3);                                  \
+                    G4P_LDB_GROUP_V(bS, vb_, b2, 1);                                                   \
+                    if (NSPLIT == 3) G4P_LDB_GROUP_V(bS, vb_, b2, 3);                                  \
                 }                                                                               \
             }                                                                                   \
         }                                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+        if constexpr (!XT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
         G4P_STAMP(3);                                                                           \
         { const int c_ = cur; cur = nxt1; nxt1 = nxt2; nxt2 = c_; }                             \
     } while (0)
@@ -1008,10 +1042,11 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
         dma_a(nk > 1 ? 1 : 0, 1);
         int c0 = 0, c1 = 1, c2 = 2;
 #pragma unroll 1
-        for (int t = 0; t < nk; ++t) {
+        // (XT: barrier k certifies A(k) landed and tile k - 1 read; there are nk + 1 of them, the prologue's and one inside every tile)
+        for (int t = 0; t < nk + (XT ? 1 : 0); ++t) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");      // A(t) landed; A(t + 1) may be in flight
             __builtin_amdgcn_s_barrier();
-            dma_a(t + 2 < nk ? t + 2 : nk - 1, c2);
+            dma_a(t + 2 < nk ? t + 2 : nk - 1, c2, XB_GEMM_TAIL == 0 || t + 2 < nk);
             const int c_ = c0; c0 = c1; c1 = c2; c2 = c_;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1047,6 +1082,14 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
             G4P_LDB_GROUP(bO, b1, 1); if (NSPLIT == 3) G4P_LDB_GROUP(bO, b1, 3);
         }
     }
+    if constexpr (XT) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NB + NA) : "memory");      // A(0) landed
+        G4P_SB();
+        __builtin_amdgcn_s_barrier();
+        G4P_SB();
+        G4P_RD16(xl, smem_raw, 1, 0);
+        G4P_RD16(xh, smem_raw, 0, 0);
+    }
     int t = 0;
 #pragma unroll 1
     for (; t + 1 < nk; t += 2) {
@@ -1067,6 +1110,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4p_kernel(xb::GemmParams p)
 #undef G4P_TILE
 #undef G4P_LDB
 #undef G4P_LDB_GROUP
+#undef G4P_LDB_GROUP_V
 #undef G4P_WAIT2
 #undef G4P_WAIT4
 #undef G4P_RD_H
