@@ -64,7 +64,9 @@ def test_encoder_small_golden(name, lstm_mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("features,nb,L,N", [(64, 5, 600, 3), (96, 4, 800, 70), (128, 6, 400, 2)])
+# (features 32 / 64 / 96: ONE, two and three k-tiles per GEMM workgroup -- the shortest trips through the k loop's prologue, its barrier between
+#  MFMA phases 2 and 3 and its past-the-end requests, csrc/xb_encoder.hip XB_GEMM_XTILE / XB_GEMM_TAIL)
+@pytest.mark.parametrize("features,nb,L,N", [(32, 6, 500, 5), (64, 5, 600, 3), (96, 4, 800, 70), (128, 6, 400, 2)])
 def test_encoder_vs_oracle(features, nb, L, N):
     keys, shapes = encoder_shapes(features, nb)
     sd = seeded_state_dict(keys, shapes, seed=features + nb)
